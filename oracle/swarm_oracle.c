@@ -1,0 +1,1022 @@
+/*
+ * swarm_oracle.c -- CPU restatement of the Swarm-NG ensemble-integrator hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see swarm_oracle.h).  Plain C, scalar, one system at a time.
+ * Every function cites the reference file:line (paths under /root/reference/src) it follows.
+ * Build with -ffp-contract=off so the arithmetic is the un-fused x86-64 arithmetic the
+ * reference's golden vectors were produced with (test/integrators/generate.sh, g++ on x86-64).
+ *
+ * "GPU form" functions restate the arithmetic ORDER of the reference's CUDA kernels
+ * (pair map order, separate sun/planet accumulators, factored corrector); they are pinned
+ * only through the reference's own tolerance test (ctest: 1e-8 against the hermite_cpu
+ * goldens, cmake/test_integrators.cmake:33-39), not bit-for-bit: "parity unpinned" at the
+ * bit level for hermite/hermite_adap/rkck/mvs/euler/verlet/midpoint GPU kernels.
+ */
+#include "swarm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NB ORC_MAX_NBOD
+#define NP (NB * (NB - 1) / 2)
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-system working view                                                                    */
+typedef struct {
+    int nbod;
+    double (*pos)[3];
+    double (*vel)[3];
+    double *mass;
+    double *time;
+    int32_t *state;
+    int32_t *id;
+    int number; /* array index of the system */
+} sysref;
+
+static sysref sys_at(const orc_ensemble *e, int i) {
+    sysref s;
+    s.nbod = e->nbod;
+    s.pos = (double(*)[3])(e->pos + (size_t)i * e->nbod * 3);
+    s.vel = (double(*)[3])(e->vel + (size_t)i * e->nbod * 3);
+    s.mass = e->mass + (size_t)i * e->nbod;
+    s.time = e->time + i;
+    s.state = e->state + i;
+    s.id = e->id + i;
+    s.number = i;
+    return s;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* pair map: swarm/gpu/pair_calculation.hpp:4-23                                              */
+int orc_pair_first(int nbod, int ij) {
+    int i = nbod - 1 - ij / (nbod / 2);
+    int j = ij % (nbod / 2);
+    if (j < i) return i;
+    return nbod - 1 - i - nbod % 2 + 1;
+}
+int orc_pair_second(int nbod, int ij) {
+    int i = nbod - 1 - ij / (nbod / 2);
+    int j = ij % (nbod / 2);
+    if (j < i) return j;
+    return nbod - 1 - j - nbod % 2;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* generate_ensemble: swarm/utils.cpp:63-103 (deterministic in this fork, theta = bod*pi/4)    */
+void orc_generate(const orc_ensemble *e, double spacing_factor, double planet_mass,
+                  double ejection_factor) {
+    for (int i = 0; i < e->nsys; i++) {
+        sysref s = sys_at(e, i);
+        double mass_sun = 1.;
+        s.mass[0] = mass_sun;
+        for (int c = 0; c < 3; c++) s.pos[0][c] = 0, s.vel[0][c] = 0;
+        for (int bod = 1; bod < e->nbod; ++bod) {
+            double rmag = 10 * pow(spacing_factor, (int)(bod - 1));
+            double vmag = sqrt(2 * mass_sun / rmag) * ejection_factor;
+            double theta = bod * M_PI / 4;
+            s.pos[bod][0] = rmag * cos(theta);
+            s.pos[bod][1] = rmag * sin(theta);
+            s.pos[bod][2] = 0;
+            s.vel[bod][0] = -vmag * sin(theta);
+            s.vel[bod][1] = vmag * cos(theta);
+            s.vel[bod][2] = 0.;
+            s.mass[bod] = planet_mass;
+        }
+        *s.state = ORC_ACTIVE;
+        *s.time = 0;
+        *s.id = i;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* snapshot record: swarm/log/log.hpp:313-326, log/types.hpp:37-56,
+ * gpulog/bits/gpulog_msg_layout.h:112-204, gpulog_types.h:60-99         */
+int64_t orc_snapshot_record_size(int nbod) {
+    int64_t len = 32 + 64 * (int64_t)nbod;
+    return (len + 15) / 16 * 16;
+}
+
+static void log_system(orc_log *log, const sysref *s) {
+    if (!log || !log->buf) return;
+    int64_t len = orc_snapshot_record_size(s->nbod);
+    /* gpulog_write.h:14-22: reserve, roll back on overflow and drop the record */
+    uint8_t *r = 0;
+#ifdef _OPENMP
+#pragma omp critical(orc_log_cursor) /* gpulog_log.h:140-150 */
+#endif
+    {
+        if (log->len + len > log->cap)
+            log->dropped++;
+        else {
+            r = log->buf + log->len;
+            log->len += len;
+        }
+    }
+    if (!r) return;
+    memset(r, 0, (size_t)len);
+    int32_t msgid = 1 /* EVT_SNAPSHOT */, ilen = (int32_t)len, nbod = s->nbod;
+    memcpy(r + 0, &msgid, 4);
+    memcpy(r + 4, &ilen, 4);
+    memcpy(r + 8, s->time, 8);
+    memcpy(r + 16, s->id, 4);
+    memcpy(r + 20, s->state, 4);
+    memcpy(r + 24, &nbod, 4);
+    for (int b = 0; b < s->nbod; b++) {
+        uint8_t *q = r + 32 + 64 * b;
+        int32_t bid = b;
+        memcpy(q + 0, s->pos[b], 24);
+        memcpy(q + 24, s->vel[b], 24);
+        memcpy(q + 48, &s->mass[b], 8);
+        memcpy(q + 56, &bid, 4);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* monitors                                                                                   */
+typedef struct {
+    const orc_monitor *p;
+    sysref *s;
+    orc_log *log;
+    int ej_met, ce_met;   /* condition_met of each sub-monitor */
+    double next_log_time; /* log_time_interval.hpp:118-119 */
+} monitor;
+
+static void mon_init(monitor *m, const orc_monitor *p, sysref *s, orc_log *log) {
+    m->p = p;
+    m->s = s;
+    m->log = log;
+    m->ej_met = 0;
+    m->ce_met = 0;
+    m->next_log_time = *s->time;
+}
+
+/* stop_on_ejection::test_body, monitors/stop_on_ejection.hpp:108-138 */
+static int ej_test_body(const monitor *m, int b) {
+    const sysref *s = m->s;
+    double x = s->pos[b][0], y = s->pos[b][1], z = s->pos[b][2];
+    double vx = s->vel[b][0], vy = s->vel[b][1], vz = s->vel[b][2];
+    double r = sqrt(x * x + y * y + z * z); /* ensemble.hpp:192-205 */
+    if (r < m->p->rmax) return 0;
+    double rdotv = x * vx + y * vy + z * vz;
+    if (rdotv <= 0.) return 0;
+    double speed_sq = vx * vx + vy * vy + vz * vz;
+    double epp = 0.5 * speed_sq * r / s->mass[b] - 1.;
+    if (fabs(epp) < 1e-4) return 1;
+    if (epp > 0) return 1;
+    return 0;
+}
+
+/* stop_on_ejection::pass_one, stop_on_ejection.hpp:177-193; returns need_full_test */
+static int ej_pass_one(monitor *m) {
+    const orc_monitor *p = m->p;
+    int need_full_test = 0;
+    m->ej_met = 0;
+    if (p->deactivate_on_ejection || p->log_on_ejection || p->verbose_on_ejection) {
+        for (int b = 1; b < m->s->nbod; b++) m->ej_met = m->ej_met || ej_test_body(m, b);
+        if (m->ej_met && p->log_on_ejection) need_full_test = 1;
+    }
+    return need_full_test;
+}
+
+/* stop_on_close_encounter::check_close_encounters, stop_on_close_encounter.hpp:124-142 */
+static int ce_check(const monitor *m, int i, int j) {
+    const sysref *s = m->s;
+    double dx = s->pos[i][0] - s->pos[j][0], dy = s->pos[i][1] - s->pos[j][1],
+           dz = s->pos[i][2] - s->pos[j][2];
+    double d = sqrt(dx * dx + dy * dy + dz * dz); /* ensemble.hpp:360-369 */
+    double GM = s->mass[0];
+    double ri = sqrt(s->pos[i][0] * s->pos[i][0] + s->pos[i][1] * s->pos[i][1] +
+                     s->pos[i][2] * s->pos[i][2]);
+    double a = 0.5 * (ri + ri); /* the reference uses body i twice (L130) */
+    double rH3 = (s->mass[i] + s->mass[j]) / (3. * GM) * a * a * a;
+    double dmin = m->p->close_approach;
+    return d * d * d < dmin * dmin * dmin * rH3;
+}
+
+/* stop_on_close_encounter::pass_one, stop_on_close_encounter.hpp:101-115 */
+static int ce_pass_one(monitor *m) {
+    const orc_monitor *p = m->p;
+    int need_full_test = 0;
+    m->ce_met = 0;
+    if (p->deactivate_on_close_encounter || p->log_on_close_encounter ||
+        p->verbose_on_close_encounter) {
+        for (int b = 2; b < m->s->nbod; b++)
+            for (int d = 1; d < b; d++) m->ce_met = m->ce_met || ce_check(m, b, d);
+        if (m->ce_met && p->log_on_close_encounter) need_full_test = 1;
+    }
+    return need_full_test;
+}
+
+/* pass_one of the bound monitor; returns "thread needs std coordinates" */
+static int mon_pass_one(monitor *m) {
+    switch (m->p->kind) {
+    case ORC_MON_EJECTION:
+        return ej_pass_one(m);
+    case ORC_MON_LOG_INTERVAL: /* log_time_interval.hpp:98-111 */
+        m->ej_met = 0;
+        if (m->p->log_interval != 0.) {
+            if (*m->s->time >= m->next_log_time) {
+                m->ej_met = 1;
+                m->next_log_time += m->p->log_interval;
+            }
+        }
+        return m->ej_met;
+    case ORC_MON_EJECTION_OR_CLOSE: /* composites.hpp:199-200, short-circuit || */
+        return ej_pass_one(m) || ce_pass_one(m);
+    }
+    return 0;
+}
+
+/* pass_two: stop_on_ejection.hpp:196-201, stop_on_close_encounter.hpp:118-123 */
+static void mon_pass_two(monitor *m) {
+    const orc_monitor *p = m->p;
+    if (p->kind == ORC_MON_EJECTION || p->kind == ORC_MON_EJECTION_OR_CLOSE)
+        if (m->ej_met && p->deactivate_on_ejection) *m->s->state = ORC_DISABLED;
+    if (p->kind == ORC_MON_EJECTION_OR_CLOSE)
+        if (m->ce_met && p->deactivate_on_close_encounter) *m->s->state = ORC_DISABLED;
+}
+
+static int mon_need_to_log(const monitor *m) {
+    const orc_monitor *p = m->p;
+    switch (p->kind) {
+    case ORC_MON_EJECTION:
+        return p->log_on_ejection && m->ej_met;
+    case ORC_MON_LOG_INTERVAL:
+        return p->log_interval != 0. && m->ej_met;
+    case ORC_MON_EJECTION_OR_CLOSE:
+        return (p->log_on_ejection && m->ej_met) || (p->log_on_close_encounter && m->ce_met);
+    }
+    return 0;
+}
+
+/* Monitor::operator()(thread_in_system): pass_one, pass_two, then log (e.g.
+ * stop_on_ejection.hpp:140-146) */
+static void mon_call(monitor *m) {
+    mon_pass_one(m);
+    mon_pass_two(m);
+    if (mon_need_to_log(m)) log_system(m->log, m->s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CPU-order force: integrators/hermite_cpu.hpp:74-112                                        */
+static void cpu_calc_forces(const sysref *s, double acc[][3], double jerk[][3]) {
+    const int nbod = s->nbod;
+    for (int b = 0; b < nbod; b++)
+        for (int c = 0; c < 3; c++) acc[b][c] = 0, jerk[b][c] = 0;
+    for (int i = 0; i < nbod - 1; i++)
+        for (int j = i + 1; j < nbod; j++) {
+            double dx[3] = {s->pos[j][0] - s->pos[i][0], s->pos[j][1] - s->pos[i][1],
+                            s->pos[j][2] - s->pos[i][2]};
+            double dv[3] = {s->vel[j][0] - s->vel[i][0], s->vel[j][1] - s->vel[i][1],
+                            s->vel[j][2] - s->vel[i][2]};
+            double r2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+            double rinv = 1 / (sqrt(r2) * r2);
+            double rv = (dx[0] * dv[0] + dx[1] * dv[1] + dx[2] * dv[2]) * 3. / r2;
+            const double scalar_i = +rinv * s->mass[j];
+            for (int c = 0; c < 3; c++) {
+                acc[i][c] += dx[c] * scalar_i;
+                jerk[i][c] += (dv[c] - dx[c] * rv) * scalar_i;
+            }
+            const double scalar_j = -rinv * s->mass[i];
+            for (int c = 0; c < 3; c++) {
+                acc[j][c] += dx[c] * scalar_j;
+                jerk[j][c] += (dv[c] - dx[c] * rv) * scalar_j;
+            }
+        }
+}
+
+/* hermite_cpu::integrate_system, integrators/hermite_cpu.hpp:115-197 */
+static void hermite_cpu_system(sysref s, const orc_params *P, const orc_monitor *M, orc_log *log,
+                               int64_t *accepted) {
+    const int nbod = s.nbod;
+    double pre_pos[NB][3], pre_vel[NB][3], acc0[NB][3], acc1[NB][3], jerk0[NB][3], jerk1[NB][3];
+    cpu_calc_forces(&s, acc0, jerk0);
+    monitor mon;
+    mon_init(&mon, M, &s, log);
+    for (int iter = 0; (iter < P->max_iterations) && *s.state == ORC_ACTIVE; iter++) {
+        double h = P->time_step;
+        if (*s.time + h > P->destination_time) h = P->destination_time - *s.time;
+        for (int b = 0; b < nbod; b++)
+            for (int c = 0; c < 3; c++) {
+                s.pos[b][c] += h * (s.vel[b][c] + h * 0.5 * (acc0[b][c] + h / 3 * jerk0[b][c]));
+                s.vel[b][c] += h * (acc0[b][c] + h * 0.5 * jerk0[b][c]);
+            }
+        for (int b = 0; b < nbod; b++)
+            for (int c = 0; c < 3; c++) pre_pos[b][c] = s.pos[b][c], pre_vel[b][c] = s.vel[b][c];
+        for (int round = 0; round < 2; round++) {
+            cpu_calc_forces(&s, acc1, jerk1);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    s.pos[b][c] = pre_pos[b][c] + (.1 - .25) * (acc0[b][c] - acc1[b][c]) * h * h -
+                                  1 / 60.0 * (7 * jerk0[b][c] + 2 * jerk1[b][c]) * h * h * h;
+                    s.vel[b][c] = pre_vel[b][c] + (-.5) * (acc0[b][c] - acc1[b][c]) * h -
+                                  1 / 12.0 * (5 * jerk0[b][c] + jerk1[b][c]) * h * h;
+                }
+        }
+        for (int b = 0; b < nbod; b++)
+            for (int c = 0; c < 3; c++) acc0[b][c] = acc1[b][c], jerk0[b][c] = jerk1[b][c];
+        *s.time += h;
+        if (accepted) (*accepted)++;
+        if (*s.state == ORC_ACTIVE) {
+            mon_call(&mon);
+            if (*s.time > P->destination_time - 1e-12) *s.state = ORC_INACTIVE;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* GPU-order force, acc+jerk: swarm/gpu/gravitation_accjerk.hpp:92-116 (calc_pair) and
+ * 129-165 (sum): pairs in pair-map order, separate sun/planet accumulators.                  */
+static void gpu_accjerk(const sysref *s, double acc[][3], double jerk[][3]) {
+    const int nbod = s->nbod, P = nbod * (nbod - 1) / 2;
+    double sa[NP][3], sj[NP][3];
+    for (int ij = 0; ij < P; ij++) {
+        int i = orc_pair_first(nbod, ij), j = orc_pair_second(nbod, ij);
+        double dx[3] = {s->pos[j][0] - s->pos[i][0], s->pos[j][1] - s->pos[i][1],
+                        s->pos[j][2] - s->pos[i][2]};
+        double dv[3] = {s->vel[j][0] - s->vel[i][0], s->vel[j][1] - s->vel[i][1],
+                        s->vel[j][2] - s->vel[i][2]};
+        double r2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+        double jerk_mag = (dx[0] * dv[0] + dx[1] * dv[1] + dx[2] * dv[2]) * 3.0 / r2;
+        double acc_mag = (1.0 / sqrt(r2)) / r2; /* rsqrt(r2) / r2 */
+        for (int c = 0; c < 3; c++) {
+            sa[ij][c] = dx[c] * acc_mag;
+            sj[ij][c] = (dv[c] - dx[c] * jerk_mag) * acc_mag;
+        }
+    }
+    for (int b = 0; b < nbod; b++)
+        for (int c = 0; c < 3; c++) {
+            double ap = 0.0, as = 0.0, jp = 0.0, js = 0.0;
+            for (int d = 0; d < P; d++) {
+                int x = orc_pair_first(nbod, d), y = orc_pair_second(nbod, d);
+                if (x == b) {
+                    if (y == 0) {
+                        as += sa[d][c] * s->mass[y];
+                        js += sj[d][c] * s->mass[y];
+                    } else {
+                        ap += sa[d][c] * s->mass[y];
+                        jp += sj[d][c] * s->mass[y];
+                    }
+                } else if (y == b) {
+                    if (x == 0) {
+                        as -= sa[d][c] * s->mass[x];
+                        js -= sj[d][c] * s->mass[x];
+                    } else {
+                        ap -= sa[d][c] * s->mass[x];
+                        jp -= sj[d][c] * s->mass[x];
+                    }
+                }
+            }
+            acc[b][c] = as + ap;
+            jerk[b][c] = js + jp;
+        }
+}
+
+/* GPU-order force, acc only: swarm/gpu/gravitation_acc.hpp:57-74 (calc_pair), 116-139
+ * (sum_acc), 96-114 (sum_acc_planets).  shared[][] is kept for Verlet's one_over_r.          */
+static void gpu_acc_pairs(const sysref *s, double sa[][3]) {
+    const int nbod = s->nbod, P = nbod * (nbod - 1) / 2;
+    for (int ij = 0; ij < P; ij++) {
+        int i = orc_pair_first(nbod, ij), j = orc_pair_second(nbod, ij);
+        double dx[3] = {s->pos[j][0] - s->pos[i][0], s->pos[j][1] - s->pos[i][1],
+                        s->pos[j][2] - s->pos[i][2]};
+        double r2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+        double acc_mag = (1.0 / sqrt(r2)) / r2;
+        for (int c = 0; c < 3; c++) sa[ij][c] = dx[c] * acc_mag;
+    }
+}
+static void gpu_acc_sum(const sysref *s, double sa[][3], double acc[][3], int planets_only) {
+    const int nbod = s->nbod, P = nbod * (nbod - 1) / 2;
+    for (int b = 0; b < nbod; b++)
+        for (int c = 0; c < 3; c++) {
+            double ap = 0, as = 0;
+            for (int d = 0; d < P; d++) {
+                int x = orc_pair_first(nbod, d), y = orc_pair_second(nbod, d);
+                if (x == b) {
+                    if (y == 0)
+                        as += sa[d][c] * s->mass[y];
+                    else
+                        ap += sa[d][c] * s->mass[y];
+                } else if (y == b) {
+                    if (x == 0)
+                        as -= sa[d][c] * s->mass[x];
+                    else
+                        ap -= sa[d][c] * s->mass[x];
+                }
+            }
+            acc[b][c] = planets_only ? ap : as + ap;
+        }
+}
+static void gpu_acc(const sysref *s, double acc[][3]) {
+    double sa[NP][3];
+    gpu_acc_pairs(s, sa);
+    gpu_acc_sum(s, sa, acc, 0);
+}
+
+/* hermite<Monitor,Grav>::kernel, integrators/hermite_integrator.hpp:74-187.
+ * adaptive != 0: hermite_adap::kernel + calc_adaptive_time_step, hermite_adap.hpp:68-201.   */
+static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor *M, orc_log *log,
+                               int adaptive, int64_t *accepted) {
+    const int nbod = s.nbod;
+    double pos[NB][3], vel[NB][3], acc0[NB][3], jerk0[NB][3], acc1[NB][3], jerk1[NB][3];
+    double pre_pos[NB][3], pre_vel[NB][3];
+    monitor mon;
+    mon_init(&mon, M, &s, log);
+    memcpy(pos, s.pos, sizeof(double) * 3 * nbod);
+    memcpy(vel, s.vel, sizeof(double) * 3 * nbod);
+    if (adaptive) mon_call(&mon); /* hermite_adap.hpp:130: monitor runs once before the loop */
+    gpu_accjerk(&s, acc0, jerk0);
+    for (int iter = 0; (iter < P->max_iterations) && *s.state == ORC_ACTIVE; iter++) {
+        double h;
+        if (adaptive) { /* hermite_adap.hpp:69-98 */
+            double tf = 0;
+            for (int b = 0; b < nbod; b++) {
+                double a2 = acc0[b][0] * acc0[b][0] + acc0[b][1] * acc0[b][1] + acc0[b][2] * acc0[b][2];
+                double j2 =
+                    jerk0[b][0] * jerk0[b][0] + jerk0[b][1] * jerk0[b][1] + jerk0[b][2] * jerk0[b][2];
+                double ratio = j2 / a2;
+                tf = (b == 0) ? ratio : tf + ratio;
+            }
+            h = (1.0 / sqrt(tf)) * P->time_step_factor + P->min_time_step;
+        } else
+            h = P->time_step;
+        if (*s.time + h > P->destination_time) h = P->destination_time - *s.time;
+        for (int b = 0; b < nbod; b++)
+            for (int c = 0; c < 3; c++) {
+                pos[b][c] = pos[b][c] + h * (vel[b][c] + (h * 0.5) * (acc0[b][c] + (h / 3.0) * jerk0[b][c]));
+                vel[b][c] = vel[b][c] + h * (acc0[b][c] + (h * 0.5) * jerk0[b][c]);
+                pre_pos[b][c] = pos[b][c], pre_vel[b][c] = vel[b][c];
+            }
+        for (int round = 0; round < 2; round++) {
+            memcpy(s.pos, pos, sizeof(double) * 3 * nbod); /* calcForces stores pos/vel first */
+            memcpy(s.vel, vel, sizeof(double) * 3 * nbod);
+            gpu_accjerk(&s, acc1, jerk1);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    pos[b][c] = pre_pos[b][c] +
+                                ((0.1 - 0.25) * (acc0[b][c] - acc1[b][c]) -
+                                 1.0 / 60.0 * (7.0 * jerk0[b][c] + 2.0 * jerk1[b][c]) * h) * h * h;
+                    vel[b][c] = pre_vel[b][c] +
+                                ((-0.5) * (acc0[b][c] - acc1[b][c]) -
+                                 1.0 / 12.0 * (5.0 * jerk0[b][c] + jerk1[b][c]) * h) * h;
+                }
+        }
+        memcpy(acc0, acc1, sizeof(double) * 3 * nbod);
+        memcpy(jerk0, jerk1, sizeof(double) * 3 * nbod);
+        memcpy(s.pos, pos, sizeof(double) * 3 * nbod);
+        memcpy(s.vel, vel, sizeof(double) * 3 * nbod);
+        *s.time += h;
+        if (accepted) (*accepted)++;
+        mon_call(&mon);
+        if (*s.state == ORC_ACTIVE) {
+            if (adaptive ? (*s.time >= P->destination_time)
+                         : (*s.time > P->destination_time - 1e-12))
+                *s.state = ORC_INACTIVE;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rkck<Adapt,Monitor,Grav>::kernel, integrators/rkck_integrator.hpp:90-294.
+ * Deviation (documented in DESIGN.md): after a REJECTED attempt the reference leaves p6^2,v6^2
+ * in the global ensemble (L221) until the next force evaluation rewrites them; if the launch's
+ * iteration budget ends on a reject those squares survive.  The oracle restores pos/vel.     */
+static void rkck_system(sysref s, const orc_params *P, const orc_monitor *M, orc_log *log,
+                        int adaptive, int64_t *accepted, int64_t *attempted) {
+    const double b1 = 1.0 / 5.0;
+    const double b2[] = {3.0 / 40.0, 9.0 / 40.0};
+    const double b3[] = {0.3, -0.9, 1.2};
+    const double b4[] = {-11.0 / 54.0, 2.5, -70.0 / 27.0, 35.0 / 27.0};
+    const double b5[] = {1631.0 / 55296.0, 175.0 / 512.0, 575.0 / 13824.0, 44275.0 / 110592.0,
+                         253.0 / 4096.0};
+    const double b6[] = {37.0 / 378.0, 0, 250.0 / 621.0, 125.0 / 594.0, 0, 512.0 / 1771.0};
+    const double ecc[] = {37.0 / 378.0 - 2825.0 / 27648.0, 0.0, 250.0 / 621.0 - 18575.0 / 48384.0,
+                          125.0 / 594.0 - 13525.0 / 55296.0, -277.00 / 14336.0, 512.0 / 1771.0 - 0.25};
+    const int nbod = s.nbod;
+    const int iteration_count = (int)(P->destination_time / P->max_time_step); /* L75 */
+    monitor mon;
+    mon_init(&mon, M, &s, log);
+    double time_step = P->max_time_step;
+    double pos[NB][3], vel[NB][3];
+    memcpy(pos, s.pos, sizeof(double) * 3 * nbod);
+    memcpy(vel, s.vel, sizeof(double) * 3 * nbod);
+    mon_call(&mon); /* L140 */
+    double kv[6][NB][3], ka[6][NB][3], p6[NB][3], v6[NB][3], pe[NB][3], ve[NB][3];
+    for (int iter = 0; (iter < iteration_count) && *s.state == ORC_ACTIVE; iter++) {
+        double h = time_step;
+        if (*s.time + h > P->destination_time) h = P->destination_time - *s.time;
+        /* stage loop: stage k evaluates acc at (p_{k-1}, v_{k-1}); k_vel = v_{k-1} */
+        double sp[NB][3], sv[NB][3];
+        memcpy(sp, pos, sizeof(sp));
+        memcpy(sv, vel, sizeof(sv));
+        for (int k = 0; k < 6; k++) {
+            memcpy(s.pos, sp, sizeof(double) * 3 * nbod);
+            memcpy(s.vel, sv, sizeof(double) * 3 * nbod);
+            gpu_acc(&s, ka[k]);
+            memcpy(kv[k], sv, sizeof(double) * 3 * nbod);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    double sumv, suma;
+#define KV(i) kv[i][b][c]
+#define KA(i) ka[i][b][c]
+                    switch (k) {
+                    case 0:
+                        sp[b][c] = pos[b][c] + h * b1 * KV(0);
+                        sv[b][c] = vel[b][c] + h * b1 * KA(0);
+                        continue;
+                    case 1:
+                        sumv = b2[0] * KV(0) + b2[1] * KV(1);
+                        suma = b2[0] * KA(0) + b2[1] * KA(1);
+                        break;
+                    case 2:
+                        sumv = b3[0] * KV(0) + b3[1] * KV(1) + b3[2] * KV(2);
+                        suma = b3[0] * KA(0) + b3[1] * KA(1) + b3[2] * KA(2);
+                        break;
+                    case 3:
+                        sumv = b4[0] * KV(0) + b4[1] * KV(1) + b4[2] * KV(2) + b4[3] * KV(3);
+                        suma = b4[0] * KA(0) + b4[1] * KA(1) + b4[2] * KA(2) + b4[3] * KA(3);
+                        break;
+                    case 4:
+                        sumv = b5[0] * KV(0) + b5[1] * KV(1) + b5[2] * KV(2) + b5[3] * KV(3) +
+                               b5[4] * KV(4);
+                        suma = b5[0] * KA(0) + b5[1] * KA(1) + b5[2] * KA(2) + b5[3] * KA(3) +
+                               b5[4] * KA(4);
+                        break;
+                    default:
+                        sumv = b6[0] * KV(0) + b6[1] * KV(1) + b6[2] * KV(2) + b6[3] * KV(3) +
+                               b6[4] * KV(4) + b6[5] * KV(5);
+                        suma = b6[0] * KA(0) + b6[1] * KA(1) + b6[2] * KA(2) + b6[3] * KA(3) +
+                               b6[4] * KA(4) + b6[5] * KA(5);
+                        break;
+                    }
+                    sp[b][c] = pos[b][c] + h * sumv;
+                    sv[b][c] = vel[b][c] + h * suma;
+                }
+        }
+        for (int b = 0; b < nbod; b++)
+            for (int c = 0; c < 3; c++) {
+                p6[b][c] = sp[b][c];
+                v6[b][c] = sv[b][c];
+                pe[b][c] = h * (ecc[0] * KV(0) + ecc[1] * KV(1) + ecc[2] * KV(2) + ecc[3] * KV(3) +
+                                ecc[4] * KV(4) + ecc[5] * KV(5));
+                ve[b][c] = h * (ecc[0] * KA(0) + ecc[1] * KA(1) + ecc[2] * KA(2) + ecc[3] * KA(3) +
+                                ecc[4] * KA(4) + ecc[5] * KA(5));
+            }
+#undef KV
+#undef KA
+        int accept_step = 1;
+        if (adaptive) { /* L204-269 */
+            const float step_grow_power = -1. / (5 + 1.);
+            const float step_shrink_power = -1. / 5;
+            const float step_guess_safety_factor = 0.9;
+            const float step_grow_max_factor = 5.0;
+            const float step_shrink_min_factor = 0.2;
+            double max_error = 0;
+            for (int i = 0; i < nbod; i++) {
+                double pos_error_mag = pe[i][0] * pe[i][0] + pe[i][1] * pe[i][1] + pe[i][2] * pe[i][2];
+                double pos_mag = p6[i][0] * p6[i][0] + p6[i][1] * p6[i][1] + p6[i][2] * p6[i][2];
+                double pen = pos_error_mag / pos_mag;
+                double vel_error_mag = ve[i][0] * ve[i][0] + ve[i][1] * ve[i][1] + ve[i][2] * ve[i][2];
+                double vel_mag = v6[i][0] * v6[i][0] + v6[i][1] * v6[i][1] + v6[i][2] * v6[i][2];
+                double ven = vel_error_mag / vel_mag;
+                max_error = fmax(fmax(pen, ven), max_error); /* CUDA max(double,double) */
+            }
+            double normalized_error = max_error / P->error_tolerance;
+            double step_guess_power = (normalized_error < 1.) ? step_grow_power : step_shrink_power;
+            double step_change_factor =
+                ((normalized_error < 0.5) || (normalized_error > 1.0))
+                    ? step_guess_safety_factor * pow(normalized_error, 0.5 * step_guess_power)
+                    : 1.0;
+            double new_time_step =
+                (normalized_error > 1.)
+                    ? fmax(time_step * fmax(step_change_factor, (double)step_shrink_min_factor),
+                           P->min_time_step)
+                    : fmin(time_step * fmax(fmin(step_change_factor, (double)step_grow_max_factor), 1.0),
+                           P->max_time_step);
+            int accept = (normalized_error < 1.0) || (fabs(time_step - new_time_step) < 1e-10);
+            time_step = new_time_step;
+            accept_step = accept;
+        }
+        if (attempted) (*attempted)++;
+        if (accept_step) {
+            memcpy(pos, p6, sizeof(pos));
+            memcpy(vel, v6, sizeof(vel));
+            memcpy(s.pos, pos, sizeof(double) * 3 * nbod);
+            memcpy(s.vel, vel, sizeof(double) * 3 * nbod);
+            *s.time += h;
+            if (accepted) (*accepted)++;
+            mon_call(&mon);
+            if (*s.state == ORC_ACTIVE && *s.time >= P->destination_time) *s.state = ORC_INACTIVE;
+        } else {
+            memcpy(s.pos, pos, sizeof(double) * 3 * nbod);
+            memcpy(s.vel, vel, sizeof(double) * 3 * nbod);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Universal-variable Kepler drift: propagators/keplerian.hpp:61-87 (SC_prussing, including the
+ * float truncation of |y| and the float sqrt it implies), 120-159 (solvex), 175-236.         */
+static void SC_prussing(double y, double *S, double *C) {
+    if (fabs(y) < 1e-4) {
+        *S = (1.0 / 6.0) * (1.0 - y * (1.0 / 20.0) * (1.0 - y * (1.0 / 42.0) * (1.0 - y * (1.0 / 72.0))));
+        *C = (1.0 / 2.0) * (1.0 - y * (1.0 / 12.0) * (1.0 - y * (1.0 / 30.0) * (1.0 - y * (1.0 / 56.0))));
+    } else {
+        float absy = (float)y;
+        absy = (float)fabs(y);
+        double u = (double)sqrtf(absy); /* C++ overload sqrt(float) */
+        double u3 = u * u * u;
+        if (y > 0.0) {
+            *S = (u - sin(u)) / u3;
+            *C = (1.0 - cos(u)) / y;
+        } else {
+            *S = (sinh(u) - u) / u3;
+            *C = (cosh(u) - 1.0) / -y;
+        }
+    }
+}
+
+static double solvex(double r0dotv0, double alpha, double sqrtM1, double r0, double dt) {
+    const double N_LAG = 5.0;
+    double smu = sqrtM1;
+    double foo = 1.0 - r0 * alpha;
+    double sig0 = r0dotv0 / smu;
+    double x = sqrtM1 * sqrtM1 * dt * dt / r0;
+    double u = 1.0;
+    for (int i = 0; (i < 7) && !((i > 2) && (x + u == x)); i++) {
+        double x2, x3, alx2, Cp, Sp, F, dF, ddF, z;
+        x2 = x * x;
+        x3 = x2 * x;
+        alx2 = alpha * x2;
+        SC_prussing(alx2, &Sp, &Cp);
+        F = sig0 * x2 * Cp + foo * x3 * Sp + r0 * x - smu * dt;
+        dF = sig0 * x * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
+        ddF = sig0 * (1.0 - alx2 * Cp) + foo * x * (1.0 - alx2 * Sp);
+        z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
+        z = sqrt(z);
+        double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
+        if (denom == 0.0) denom = 1e-8;
+        u = N_LAG * F / denom;
+        x -= u;
+    }
+    return x;
+}
+
+static void drift_kepler(double *pp, double *vv, const double sqrtGM, const double deltaTime) {
+    double x_old = pp[0], y_old = pp[1], z_old = pp[2], vx_old = vv[0], vy_old = vv[1], vz_old = vv[2];
+    double x = x_old, y = y_old, z = z_old, vx = vx_old, vy = vy_old, vz = vz_old;
+    double r0 = sqrt(x * x + y * y + z * z);
+    double v2 = (vx * vx + vy * vy + vz * vz);
+    double r0dotv0 = (x * vx + y * vy + z * vz);
+    double GM = sqrtGM * sqrtGM;
+    double alpha = (2.0 / r0 - v2 / GM);
+    double x_p = solvex(r0dotv0, alpha, sqrtGM, r0, deltaTime);
+    double smu = sqrtGM;
+    double foo = 1.0 - r0 * alpha;
+    double sig0 = r0dotv0 / smu;
+    double x2 = x_p * x_p;
+    double x3 = x2 * x_p;
+    double alx2 = alpha * x2;
+    double Cp, Sp;
+    SC_prussing(alx2, &Sp, &Cp);
+    double r = sig0 * x_p * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
+    if (r < 0.) r = 0.;
+    double f_p = 1.0 - (x2 / r0) * Cp;
+    double g_p = deltaTime - (x3 / smu) * Sp;
+    double dfdt;
+    double dgdt = 1.0 - (x2 / r) * Cp;
+    if (fabs(g_p) > 1e-8)
+        dfdt = (f_p * dgdt - 1.0) / g_p;
+    else
+        dfdt = x_p * smu / (r * r0) * (alx2 * Sp - 1.0);
+    x = f_p * x_old + g_p * vx_old;
+    y = f_p * y_old + g_p * vy_old;
+    z = f_p * z_old + g_p * vz_old;
+    vx = dfdt * x_old + dgdt * vx_old;
+    vy = dfdt * y_old + dgdt * vy_old;
+    vz = dfdt * z_old + dgdt * vz_old;
+    pp[0] = x, pp[1] = y, pp[2] = z;
+    vv[0] = vx, vv[1] = vy, vv[2] = vz;
+}
+
+/* MVSPropagator coordinate changes, propagators/mvs.hpp:159-190 and 195-230 */
+static void mvs_to_internal(const sysref *s) {
+    const int nbod = s->nbod;
+    for (int c = 0; c < 3; c++) {
+        double pc0 = s->pos[0][c];
+        double sump = 0., sumv = 0., mtot = 0.;
+        for (int j = 0; j < nbod; ++j) {
+            const double mj = s->mass[j];
+            mtot += mj;
+            sump += mj * s->pos[j][c];
+            sumv += mj * s->vel[j][c];
+        }
+        sumv /= mtot;
+        s->vel[0][c] = sumv;
+        s->pos[0][c] = sump / mtot;
+        for (int b = 1; b < nbod; b++) {
+            s->vel[b][c] -= sumv;
+            s->pos[b][c] -= pc0;
+        }
+    }
+}
+static void mvs_to_std(const sysref *s) {
+    const int nbod = s->nbod;
+    for (int c = 0; c < 3; c++) {
+        double sump = 0., sumv = 0., mtot;
+        double m0 = s->mass[0], pc0 = s->pos[0][c], vc0 = s->vel[0][c];
+        mtot = m0;
+        for (int j = 1; j < nbod; ++j) {
+            const double mj = s->mass[j];
+            mtot += mj;
+            sump += mj * s->pos[j][c];
+            sumv += mj * s->vel[j][c];
+        }
+        sump /= mtot;
+        s->pos[0][c] -= sump;
+        s->vel[0][c] -= sumv / m0;
+        for (int b = 1; b < nbod; b++) {
+            s->pos[b][c] += pc0 - sump;
+            s->vel[b][c] += vc0;
+        }
+    }
+}
+/* MVSPropagator::drift_step, mvs.hpp:242-256.  Every (b,c) thread reads the same
+ * velocities (they are not modified by the drift), so the update is order-independent.     */
+static void mvs_drift(const sysref *s, double hby2) {
+    const int nbod = s->nbod;
+    for (int c = 0; c < 3; c++) {
+        double mv = 0;
+        for (int j = 1; j < nbod; ++j) mv += s->mass[j] * s->vel[j][c];
+        s->pos[0][c] += hby2 * s->vel[0][c];
+        for (int b = 1; b < nbod; b++) s->pos[b][c] += mv * hby2 / s->mass[0];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* generic<Prop,Mon,Grav>::kernel, swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238, with the
+ * propagators MVS (mvs.hpp:99-109,260-293), Euler (euler.hpp:101-122), Verlet
+ * (verlet.hpp:80-175) and Midpoint (midpoint.hpp:106-160).
+ * Deviation: the reference converts a whole CUDA block to standard coordinates
+ * when ANY system of the block asks (syncthreads_or, L192); here only the asking system.    */
+static void generic_system(sysref s, const orc_params *P, const orc_monitor *M, orc_log *log,
+                           int64_t *accepted) {
+    const int nbod = s.nbod, kind = P->integrator;
+    monitor mon;
+    mon_init(&mon, M, &s, log);
+    double acc_bc[NB][3];
+    double sqrtGM = 0, timestep = 0;
+    double sa[NP][3];
+    /* prop.init() */
+    if (kind == ORC_INT_MVS) {
+        sqrtGM = sqrt(s.mass[0]);
+        mvs_to_internal(&s);
+        gpu_acc_pairs(&s, sa);
+        gpu_acc_sum(&s, sa, acc_bc, 1);
+    } else if (kind == ORC_INT_VERLET) {
+        gpu_acc_pairs(&s, sa);
+    }
+#define VERLET_TIMESTEP()                                                                  \
+    do { /* verlet.hpp:112-137; one_over_r = sum of squares of shared acc (gravitation_acc.hpp:78-93) */ \
+        double factor = 0.;                                                                \
+        for (int i = 0; i < nbod; ++i) {                                                   \
+            double mi = s.mass[i];                                                         \
+            for (int j = 1; j < nbod; ++j) {                                               \
+                if (i == j) continue;                                                      \
+                double mj = s.mass[j];                                                     \
+                double oor = 0.;                                                           \
+                for (int d = 0; d < nbod * (nbod - 1) / 2; d++) {                          \
+                    int x = orc_pair_first(nbod, d), y = orc_pair_second(nbod, d);         \
+                    if (((x == i) && (y == j)) || ((x == j) && (y == i))) {                \
+                        oor += sa[d][0] * sa[d][0];                                        \
+                        oor += sa[d][1] * sa[d][1];                                        \
+                        oor += sa[d][2] * sa[d][2];                                        \
+                    }                                                                      \
+                }                                                                          \
+                factor += (mi + mj) * oor * oor * oor;                                     \
+            }                                                                              \
+        }                                                                                  \
+        factor *= P->timestep_scale * P->timestep_scale;                                   \
+        factor += 1.;                                                                      \
+        factor = 1.0 / sqrt(factor);                                                       \
+        factor *= P->max_timestep;                                                         \
+        timestep = factor;                                                                 \
+    } while (0)
+    if (kind == ORC_INT_VERLET) VERLET_TIMESTEP();
+
+    for (int iter = 0; (iter < P->max_iterations) && *s.state == ORC_ACTIVE; iter++) {
+        double max_timestep = P->destination_time - *s.time;
+        /* prop.advance() */
+        if (kind == ORC_INT_MVS) {
+            double hby2 = 0.5 * fmin(max_timestep, P->time_step);
+            mvs_drift(&s, hby2);
+            for (int b = 1; b < nbod; b++)
+                for (int c = 0; c < 3; c++) s.vel[b][c] += hby2 * acc_bc[b][c];
+            for (int b = 1; b < nbod; b++) drift_kepler(s.pos[b], s.vel[b], sqrtGM, 2.0 * hby2);
+            gpu_acc_pairs(&s, sa);
+            gpu_acc_sum(&s, sa, acc_bc, 1);
+            for (int b = 1; b < nbod; b++)
+                for (int c = 0; c < 3; c++) s.vel[b][c] += hby2 * acc_bc[b][c];
+            mvs_drift(&s, hby2);
+            *s.time += 2.0 * hby2;
+        } else if (kind == ORC_INT_EULER) {
+            double h = fmin(P->time_step, max_timestep);
+            const double third = 1.0 / 3.0;
+            double acc[NB][3], jerk[NB][3];
+            gpu_accjerk(&s, acc, jerk);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    double pos = s.pos[b][c], vel = s.vel[b][c];
+                    s.pos[b][c] = pos + h * (vel + (h * 0.5) * (acc[b][c] + (h * third) * jerk[b][c]));
+                    s.vel[b][c] = vel + h * (acc[b][c] + (h * 0.5) * jerk[b][c]);
+                }
+            *s.time += h;
+        } else if (kind == ORC_INT_VERLET) {
+            double h = timestep;
+            double h_first_half = 0.5 * h;
+            double acc[NB][3];
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) s.pos[b][c] = s.pos[b][c] + h_first_half * s.vel[b][c];
+            gpu_acc_pairs(&s, sa);
+            gpu_acc_sum(&s, sa, acc, 0);
+            VERLET_TIMESTEP();
+            double h_second_half = 0.5 * timestep;
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    double vel = s.vel[b][c] + h_first_half * acc[b][c];
+                    vel = vel + h_second_half * acc[b][c];
+                    s.vel[b][c] = vel;
+                    s.pos[b][c] = s.pos[b][c] + h_second_half * vel;
+                }
+            *s.time += h_first_half + h_second_half;
+        } else { /* midpoint */
+            double H = fmin(max_timestep, P->time_step);
+            const int n = 4;
+            double h = H / n;
+            double p_i[NB][3], p_im1[NB][3], p_im2[NB][3], v_i[NB][3], v_im1[NB][3], v_im2[NB][3];
+            double a[NB][3];
+            const size_t sz = sizeof(double) * 3 * nbod;
+            memcpy(p_im1, s.pos, sz);
+            memcpy(v_im1, s.vel, sz);
+            gpu_acc(&s, a);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    p_i[b][c] = p_im1[b][c] + h * v_im1[b][c];
+                    v_i[b][c] = v_im1[b][c] + h * a[b][c];
+                }
+            for (int i = 2; i <= n; i++) {
+                memcpy(p_im2, p_im1, sz);
+                memcpy(p_im1, p_i, sz);
+                memcpy(v_im2, v_im1, sz);
+                memcpy(v_im1, v_i, sz);
+                memcpy(s.pos, p_im1, sz);
+                memcpy(s.vel, v_im1, sz);
+                gpu_acc(&s, a);
+                for (int b = 0; b < nbod; b++)
+                    for (int c = 0; c < 3; c++) {
+                        p_i[b][c] = p_im2[b][c] + 2.0 * h * v_im1[b][c];
+                        v_i[b][c] = v_im2[b][c] + 2.0 * h * a[b][c];
+                    }
+            }
+            memcpy(s.pos, p_i, sz);
+            memcpy(s.vel, v_i, sz);
+            gpu_acc(&s, a);
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    s.pos[b][c] = 0.5 * (p_i[b][c] + p_im1[b][c] + h * v_i[b][c]);
+                    s.vel[b][c] = 0.5 * (v_i[b][c] + v_im1[b][c] + h * a[b][c]);
+                }
+            *s.time += H;
+        }
+        if (accepted) (*accepted)++;
+        /* monitor: pass_one in internal coordinates, convert only if it asks, pass_two, log */
+        int needs_std = mon_pass_one(&mon);
+        int using_std = 0;
+        if (needs_std && kind == ORC_INT_MVS) {
+            mvs_to_std(&s);
+            using_std = 1;
+        }
+        mon_pass_two(&mon);
+        if (mon_need_to_log(&mon)) log_system(log, &s);
+        if (using_std) mvs_to_internal(&s);
+        if (*s.state == ORC_ACTIVE && *s.time >= P->destination_time) *s.state = ORC_INACTIVE;
+    }
+    /* prop.shutdown() */
+    if (kind == ORC_INT_MVS) mvs_to_std(&s);
+#undef VERLET_TIMESTEP
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* one launch over all systems: hermite_cpu::launch_integrator, hermite_cpu.hpp:59-66 */
+int orc_launch(const orc_ensemble *e, const orc_params *p, const orc_monitor *m, orc_log *log,
+               const orc_counters *cnt, int threads) {
+    if (e->nbod < 3 || e->nbod > NB) return -1;
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+#endif
+    for (int i = 0; i < e->nsys; i++) {
+        sysref s = sys_at(e, i);
+        int64_t *acc = (cnt && cnt->accepted) ? cnt->accepted + i : 0;
+        int64_t *att = (cnt && cnt->attempted) ? cnt->attempted + i : 0;
+        int64_t a0 = acc ? *acc : 0;
+        switch (p->integrator) {
+        case ORC_INT_HERMITE_CPU:
+            hermite_cpu_system(s, p, m, log, acc);
+            break;
+        case ORC_INT_HERMITE:
+            hermite_gpu_system(s, p, m, log, 0, acc);
+            break;
+        case ORC_INT_HERMITE_ADAP:
+            hermite_gpu_system(s, p, m, log, 1, acc);
+            break;
+        case ORC_INT_RKCK_FIXED:
+            rkck_system(s, p, m, log, 0, acc, att);
+            break;
+        case ORC_INT_RKCK_ADAPTIVE:
+            rkck_system(s, p, m, log, 1, acc, att);
+            break;
+        default:
+            generic_system(s, p, m, log, acc);
+            break;
+        }
+        if (att && p->integrator != ORC_INT_RKCK_FIXED && p->integrator != ORC_INT_RKCK_ADAPTIVE)
+            *att += (acc ? *acc : 0) - a0;
+    }
+    return 0;
+}
+
+int orc_count_active(const orc_ensemble *e) { /* swarm/integrator.cpp:61-66 */
+    int n = 0;
+    for (int i = 0; i < e->nsys; i++)
+        if (e->state[i] == ORC_ACTIVE) n++;
+    return n;
+}
+
+/* swarm::integrator::integrate, swarm/integrator.cpp:83-100 */
+int orc_integrate(const orc_ensemble *e, const orc_params *p, const orc_monitor *m, orc_log *log,
+                  const orc_counters *cnt, int threads, int max_attempts) {
+    for (int i = 0; i < e->nsys; i++)
+        if (e->state[i] == ORC_INACTIVE) e->state[i] = ORC_ACTIVE;
+    int attempts = 0;
+    for (int i = 0; i < max_attempts; i++) {
+        int rc = orc_launch(e, p, m, log, cnt, threads);
+        if (rc) return rc;
+        attempts++;
+        if (orc_count_active(e) == 0) break;
+    }
+    return attempts;
+}
+
+/* SystemRef::calc_total_energy, swarm/types/ensemble.hpp:402-413 */
+void orc_total_energy(const orc_ensemble *e, double *energy) {
+    for (int i = 0; i < e->nsys; i++) {
+        sysref s = sys_at(e, i);
+        double K = 0.0, U = 0.0;
+        for (int b = 0; b < s.nbod; b++)
+            K += 0.5 * s.mass[b] *
+                 (s.vel[b][0] * s.vel[b][0] + s.vel[b][1] * s.vel[b][1] + s.vel[b][2] * s.vel[b][2]);
+        for (int b = 0; b < s.nbod; b++)
+            for (int j = 0; j < b; j++) {
+                double dx = s.pos[b][0] - s.pos[j][0], dy = s.pos[b][1] - s.pos[j][1],
+                       dz = s.pos[b][2] - s.pos[j][2];
+                U += -s.mass[b] * s.mass[j] / sqrt(dx * dx + dy * dy + dz * dz);
+            }
+        energy[i] = K + U;
+    }
+}
+
+/* compare_ensembles, swarm/utils.cpp:170-214 */
+int orc_compare(const orc_ensemble *a, const orc_ensemble *b, double *pos_diff, double *vel_diff,
+                double *time_diff) {
+    if (a->nsys != b->nsys || a->nbod != b->nbod) return 0;
+    *pos_diff = *vel_diff = *time_diff = 0;
+    for (int i = 0; i < a->nsys; i++) {
+        sysref s1 = sys_at(a, i), s2 = sys_at(b, i);
+        for (int j = 0; j < a->nbod; j++) {
+            double dp = 0, dv = 0;
+            for (int c = 0; c < 3; c++) {
+                dp += (s1.pos[j][c] - s2.pos[j][c]) * (s1.pos[j][c] - s2.pos[j][c]);
+                dv += (s1.vel[j][c] - s2.vel[j][c]) * (s1.vel[j][c] - s2.vel[j][c]);
+            }
+            dp = sqrt(dp), dv = sqrt(dv);
+            if (dp > *pos_diff) *pos_diff = dp;
+            if (dv > *vel_diff) *vel_diff = dv;
+        }
+        double dt = fabs(*s1.time - *s2.time) / (*s1.time + *s2.time) * 2;
+        if (dt > *time_diff) *time_diff = dt;
+    }
+    return 1;
+}
