@@ -1,0 +1,194 @@
+/*
+ * swarm_hip.h -- C-ABI of libswarm_hip.so: the MI355X (gfx950) ensemble-integrator hot path.
+ *
+ * This is the drop-in boundary for the reference's `gpu::integrator` path
+ * (/root/reference/src, cited per entry point below).  Plain pointers and sizes only; no C++
+ * or torch types cross it.  Every function returns 0 on success and a negative SWARM_HIP_E*
+ * code on failure (never throws); swarm_hip_last_error() gives the message of the calling
+ * thread's last failure.  All pointers named d_* / inside swarm_hip_ensemble_t are DEVICE
+ * pointers on the current HIP device; `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Calls are asynchronous on `stream` unless stated otherwise.
+ *
+ * Device ensemble layout ("wave chunks", replaces swarm/types/ensemble.hpp:131-150,227-238 +
+ * types/coalescedstructarray.hpp:135-140 with CHUNK 8 -> 64):
+ *   chunk k holds systems 64k .. 64k+63, one system per lane of a wavefront.
+ *   body : double [nchunk][nbod][7 + nbattr][64]   fields x,y,z,vx,vy,vz,mass,attr0..
+ *   sysd : double [nchunk][1 + nsattr][64]         fields time,attr0..
+ *   sysi : int32  [nchunk][2][64]                  fields state,id
+ *   nchunk = ceil(nsys / 64).  Lanes >= nsys in the last chunk are padding and are ignored.
+ */
+#ifndef SWARM_HIP_H
+#define SWARM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWARM_HIP_CHUNK 64
+#define SWARM_HIP_MIN_NBOD 3
+#define SWARM_HIP_MAX_NBOD 8
+
+/* error codes */
+#define SWARM_HIP_OK 0
+#define SWARM_HIP_EINVAL (-1)     /* bad argument (nbod out of range, NULL pointer, ...) */
+#define SWARM_HIP_EHIP (-2)       /* a HIP runtime call failed */
+#define SWARM_HIP_EUNSUPPORTED (-3)
+
+/* system states, swarm/types/ensemble.hpp:269-274 */
+#define SWARM_HIP_ACTIVE 0
+#define SWARM_HIP_INACTIVE 1
+#define SWARM_HIP_NEEDS_EXAM 2
+#define SWARM_HIP_DISABLED (-1)
+
+/* integrator ids = the reference's registry names (src/plugins/ *.cu) */
+enum swarm_hip_integrator {
+    SWARM_HIP_HERMITE = 1,       /* plugins/hermite.cu:40, integrators/hermite_integrator.hpp */
+    SWARM_HIP_HERMITE_ADAP = 2,  /* plugins/hermite_adap.cu:39-47, integrators/hermite_adap.hpp */
+    SWARM_HIP_RKCK_FIXED = 3,    /* plugins/rkck_fixed.cu:28, integrators/rkck_integrator.hpp */
+    SWARM_HIP_RKCK_ADAPTIVE = 4, /* plugins/rkck_adaptive.cu:27 */
+    SWARM_HIP_MVS = 5,           /* plugins/mvs.cu:37, propagators/mvs.hpp + keplerian.hpp */
+    SWARM_HIP_EULER = 6,         /* plugins/euler.cu:36, propagators/euler.hpp */
+    SWARM_HIP_VERLET = 7,        /* plugins/verlet.cu:35, propagators/verlet.hpp */
+    SWARM_HIP_MIDPOINT = 8       /* plugins/midpoint.cu:35, propagators/midpoint.hpp */
+};
+
+/* monitor bound to the plugin name */
+enum swarm_hip_monitor {
+    SWARM_HIP_MON_EJECTION = 0,          /* monitors/stop_on_ejection.hpp */
+    SWARM_HIP_MON_LOG_INTERVAL = 1,      /* monitors/log_time_interval.hpp (`*_log` names) */
+    SWARM_HIP_MON_EJECTION_OR_CLOSE = 2  /* monitors/composites.hpp:145-222 (`*_close_encounter`) */
+};
+
+typedef struct swarm_hip_ensemble {
+    int32_t nsys, nbod;
+    int32_t nbattr, nsattr; /* NUM_PLANET_ATTRIBUTES / NUM_SYSTEM_ATTRIBUTES, src/config.h.in */
+    double *body;
+    double *sysd;
+    int32_t *sysi;
+} swarm_hip_ensemble_t;
+
+/* Device event buffer: replaces gpulog::log_base {char* buffer; int* at; int buf_len}
+ * (swarm/log/gpulog/bits/gpulog_log.h:171-178).  Records are byte-compatible with the
+ * reference (EVT_SNAPSHOT layout: log/log.hpp:313-326, log/types.hpp:37-56).
+ * d_cursor[0] = bytes used, d_cursor[1] = records dropped because the buffer was full
+ * (the reference drops them silently, bits/gpulog_write.h:14-22). */
+typedef struct swarm_hip_log {
+    uint8_t *d_buf;
+    int32_t *d_cursor; /* int32[2] */
+    int32_t capacity;  /* bytes */
+} swarm_hip_log_t;
+
+/* One kernel launch of an integrator plugin: what `launch_integrator()` ->
+ * launch_templatized_integrator (swarm/gpu/helpers.hpp:167-238) does in the reference.
+ * Config keys are the reference's (.cfg names in comments). */
+typedef struct swarm_hip_launch {
+    int32_t integrator;     /* enum swarm_hip_integrator          integrator=            */
+    int32_t monitor;        /* enum swarm_hip_monitor             (by plugin name)       */
+    int32_t max_iterations; /* steps per launch per system        max_iterations=        */
+    int32_t block_size;     /* threads per workgroup, multiple of 64; 0 = default;
+                               the analogue of system_per_block=                          */
+    double destination_time; /*                                   destination_time=      */
+    double time_step;        /* hermite, mvs, euler, midpoint     time_step=             */
+    double time_step_factor; /* hermite_adap                      time_step_factor=      */
+    double min_time_step;    /* hermite_adap, rkck                min_time_step=         */
+    double max_time_step;    /* rkck                              max_time_step=         */
+    double error_tolerance;  /* rkck                              error_tolerance=       */
+    double max_timestep;     /* verlet                            max_timestep=          */
+    double timestep_scale;   /* verlet                            timestep_scale=        */
+    /* monitors */
+    double rmax;                           /* rmax= (default FLT_MAX)                    */
+    int32_t deactivate_on_ejection;        /* deactivate_on_ejection=                    */
+    int32_t log_on_ejection;               /* log_on_ejection=                           */
+    int32_t verbose_on_ejection;           /* verbose_on_ejection= (no lprintf output)   */
+    int32_t deactivate_on_close_encounter; /* deactivate_on_close_encounter=             */
+    int32_t log_on_close_encounter;        /* log_on_close_encounter=                    */
+    int32_t verbose_on_close_encounter;    /* verbose_on_close_encounter=                */
+    double close_approach;                 /* close_approach=                            */
+    double log_interval;                   /* log_interval=                              */
+    swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
+    /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
+    uint64_t *d_steps_accepted;
+    uint64_t *d_steps_attempted;
+    void *stream;
+} swarm_hip_launch_t;
+
+/* ---- library ----------------------------------------------------------------------------- */
+/* Select `device` (hipSetDevice) and create the per-device scratch the helpers use.
+ * Replaces select_cuda_device (swarm/gpu/device_settings.cpp:52-62).  Synchronous. */
+int swarm_hip_init(int device);
+const char *swarm_hip_last_error(void);
+const char *swarm_hip_version(void);
+
+/* ---- layout helpers (host, no GPU touched) ------------------------------------------------ */
+/* Element counts, cf. ensemble::body_element_count / sys_element_count (ensemble.hpp:448-455) */
+int64_t swarm_hip_nchunk(int32_t nsys);
+size_t swarm_hip_body_bytes(int32_t nsys, int32_t nbod, int32_t nbattr);
+size_t swarm_hip_sysd_bytes(int32_t nsys, int32_t nsattr);
+size_t swarm_hip_sysi_bytes(int32_t nsys);
+int64_t swarm_hip_snapshot_record_bytes(int32_t nbod); /* 32 + 64*nbod rounded to 16 */
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* Integrate every ACTIVE system until destination_time or max_iterations steps, with the
+ * monitor fused.  = generic_kernel<Impl,T><<<>>> (swarm/gpu/helpers.hpp:124-127,198). */
+int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip_launch_t *args);
+
+/* Count systems with state == ACTIVE.  = number_of_active_systems (swarm/gpu/utilities.cu:30-64).
+ * Synchronises `stream`; result in *count. */
+int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_t *count);
+
+/* INACTIVE -> ACTIVE.  = reactivate_systems (swarm/gpu/utilities.cu:113-131) and
+ * activate_inactive_systems (swarm/integrator.cpp:83-89). */
+int swarm_hip_reactivate(const swarm_hip_ensemble_t *ens, void *stream);
+
+/* Total energy per system into d_energy[nchunk*64] (K + U, G = 1).
+ * = SystemRef::calc_total_energy (swarm/types/ensemble.hpp:402-413). */
+int swarm_hip_total_energy(const swarm_hip_ensemble_t *ens, double *d_energy, void *stream);
+
+/* Reduction over systems for the multi-GPU statistics (no counterpart kernel in the reference,
+ * which reduces on the host: energy_conservation_error_range, swarm/utils.cpp:108-121).
+ * Given d_e0/d_e1 [nsys] writes d_out[8] = {sum |dE/E0|, max |dE/E0|, min |dE/E0|, n_active,
+ * n_inactive, n_disabled, n_other, nsys}. */
+int swarm_hip_energy_stats(const swarm_hip_ensemble_t *ens, const double *d_e0, const double *d_e1,
+                           double *d_out, void *stream);
+
+/* ---- layout conversion ------------------------------------------------------------------- */
+/* Reference CoalescedStructArray image (device copies of ensemble::Body[] and ensemble::Sys[]
+ * built with ENSEMBLE_CHUNK_SIZE = ref_chunk; swarm/types/ensemble.hpp:131-150,227-238,499-517)
+ * -> wave chunks, and back.  This is what a reference-side `gpu::integrator` calls after
+ * upload_ensemble / before download_ensemble (swarm/integrator.hpp:266-273). */
+int swarm_hip_import_ref_layout(const swarm_hip_ensemble_t *ens, const void *d_ref_body,
+                                const void *d_ref_sys, int32_t ref_chunk, void *stream);
+int swarm_hip_export_ref_layout(const swarm_hip_ensemble_t *ens, void *d_ref_body, void *d_ref_sys,
+                                int32_t ref_chunk, void *stream);
+
+/* Plain host AoS arrays <-> device wave chunks (synchronous; stages through a host buffer).
+ * pos/vel [nsys][nbod][3], mass [nsys][nbod], time [nsys], state/id [nsys],
+ * body_attr [nsys][nbod][nbattr] (may be NULL), sys_attr [nsys][nsattr] (may be NULL).
+ * = alloc_copy H2D/D2H (swarm/types/allocators.hpp:152-166) for callers without the
+ * reference's host ensemble class. */
+int swarm_hip_upload_aos(const swarm_hip_ensemble_t *ens, const double *pos, const double *vel,
+                         const double *mass, const double *time, const int32_t *state,
+                         const int32_t *id, const double *body_attr, const double *sys_attr);
+int swarm_hip_download_aos(const swarm_hip_ensemble_t *ens, double *pos, double *vel, double *mass,
+                           double *time, int32_t *state, int32_t *id, double *body_attr,
+                           double *sys_attr);
+
+/* ---- device memory convenience (hipMalloc/hipFree/hipMemcpy wrappers for FFI callers) ------ */
+int swarm_hip_malloc(void **d_ptr, size_t bytes);
+int swarm_hip_free(void *d_ptr);
+int swarm_hip_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int swarm_hip_memcpy_d2h(void *host, const void *d_ptr, size_t bytes);
+int swarm_hip_memcpy_h2d(void *d_ptr, const void *host, size_t bytes);
+int swarm_hip_synchronize(void *stream);
+/* timing on the launch stream (HIP events): elapsed ms between two marks */
+int swarm_hip_event_create(void **event);
+int swarm_hip_event_record(void *event, void *stream);
+int swarm_hip_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises stop */
+int swarm_hip_event_destroy(void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

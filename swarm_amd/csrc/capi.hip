@@ -1,0 +1,611 @@
+// capi.hip -- the extern "C" surface of libswarm_hip.so (include/swarm_hip.h) and the small
+// utility kernels (active count, reactivate, energy, statistics, layout conversion).
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "launch.hpp"
+
+namespace swh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));              \
+            return SWARM_HIP_EHIP;                                                 \
+        }                                                                          \
+    } while (0)
+
+static int check_ens(const swarm_hip_ensemble_t *ens) {
+    if (!ens) {
+        set_error("ensemble pointer is NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys < 0 || ens->nbod < SWARM_HIP_MIN_NBOD || ens->nbod > SWARM_HIP_MAX_NBOD ||
+        ens->nbattr < 0 || ens->nsattr < 0) {
+        set_error("bad ensemble shape nsys=%d nbod=%d nbattr=%d nsattr=%d (nbod must be %d..%d)", ens->nsys,
+                  ens->nbod, ens->nbattr, ens->nsattr, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD);
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys > 0 && (!ens->body || !ens->sysd || !ens->sysi)) {
+        set_error("ensemble device pointers must not be NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    return SWARM_HIP_OK;
+}
+
+static EnsView view_of(const swarm_hip_ensemble_t *ens) {
+    EnsView v;
+    v.nsys = ens->nsys;
+    v.nbod = ens->nbod;
+    v.nbf = 7 + ens->nbattr;
+    v.nsf = 1 + ens->nsattr;
+    v.body = ens->body;
+    v.sysd = ens->sysd;
+    v.sysi = ens->sysi;
+    return v;
+}
+
+// per-device scratch for the helpers (a counter), created by swarm_hip_init or lazily
+constexpr int MAX_DEV = 64;
+static int32_t *g_scratch[MAX_DEV] = {nullptr};
+
+static int scratch_for_current(int32_t **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) {
+        set_error("device ordinal %d out of range", dev);
+        return SWARM_HIP_EINVAL;
+    }
+    if (!g_scratch[dev]) HIP_TRY(hipMalloc((void **)&g_scratch[dev], 256));
+    *out = g_scratch[dev];
+    return SWARM_HIP_OK;
+}
+
+// ---- utility kernels ---------------------------------------------------------------------
+// number_of_active_systems_kernel (swarm/gpu/utilities.cu:36-64) does one atomicAdd per ACTIVE
+// system; here one per wavefront (ballot + popcount).
+__global__ void count_active_kernel(EnsView e, int32_t *out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = false;
+    if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
+    const unsigned long long m = __ballot(act);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// reactivate_systems_kernel, swarm/gpu/utilities.cu:113-131
+__global__ void reactivate_kernel(EnsView e) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= e.nsys) return;
+    int32_t *st = e.sysi + (size_t)(gid / W) * 2 * W + gid % W;
+    if (*st == SWARM_HIP_INACTIVE) *st = SWARM_HIP_ACTIVE;
+}
+
+// SystemRef::calc_total_energy, swarm/types/ensemble.hpp:402-413 (same operation order, no FMA)
+__global__ void energy_kernel(EnsView e, double *out) {
+#pragma clang fp contract(off)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= e.nsys) return;
+    const int chunk = gid / W, lane = gid % W, n = e.nbod;
+    const double *b = e.body + (size_t)chunk * n * e.nbf * W + lane;
+    double K = 0.0, U = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double *r = b + (size_t)i * e.nbf * W;
+        const double vx = r[3 * W], vy = r[4 * W], vz = r[5 * W];
+        K += 0.5 * r[6 * W] * (vx * vx + vy * vy + vz * vz);
+    }
+    for (int i = 0; i < n; i++) {
+        const double *ri = b + (size_t)i * e.nbf * W;
+        for (int j = 0; j < i; j++) {
+            const double *rj = b + (size_t)j * e.nbf * W;
+            const double dx = ri[0] - rj[0], dy = ri[W] - rj[W], dz = ri[2 * W] - rj[2 * W];
+            U += -ri[6 * W] * rj[6 * W] / sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    out[gid] = K + U;
+}
+
+// wave-level reductions (DPP/bpermute shuffles), then one atomic per wavefront
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ void atomic_max_pos(double *addr, double v) { // v >= 0
+    atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_min_pos(double *addr, double v) { // v >= 0
+    atomicMin(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void stats_init_kernel(double *out, int nsys) {
+    out[0] = 0.0;
+    out[1] = 0.0;
+    out[2] = __longlong_as_double(0x7ff0000000000000LL); // +inf
+    out[3] = out[4] = out[5] = out[6] = 0.0;
+    out[7] = (double)nsys;
+}
+
+__global__ void stats_kernel(EnsView e, const double *e0, const double *e1, double *out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = gid < e.nsys;
+    double err = 0.0;
+    int st = 12345;
+    if (in) {
+        err = fabs((e1[gid] - e0[gid]) / e0[gid]); // utils.cpp:117-118
+        st = e.sysi[(size_t)(gid / W) * 2 * W + gid % W];
+    }
+    const double s = wave_sum(in ? err : 0.0);
+    const double mx = wave_max(in ? err : 0.0);
+    const double mn = wave_min(in ? err : __longlong_as_double(0x7ff0000000000000LL));
+    const int na = __popcll(__ballot(in && st == SWARM_HIP_ACTIVE));
+    const int ni = __popcll(__ballot(in && st == SWARM_HIP_INACTIVE));
+    const int nd = __popcll(__ballot(in && st == SWARM_HIP_DISABLED));
+    const int no = __popcll(__ballot(in && st != SWARM_HIP_ACTIVE && st != SWARM_HIP_INACTIVE &&
+                                     st != SWARM_HIP_DISABLED));
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, s);
+        if (mx == mx) atomic_max_pos(out + 1, mx);
+        if (mn == mn) atomic_min_pos(out + 2, mn);
+        if (na) atomicAdd(out + 3, (double)na);
+        if (ni) atomicAdd(out + 4, (double)ni);
+        if (nd) atomicAdd(out + 5, (double)nd);
+        if (no) atomicAdd(out + 6, (double)no);
+    }
+}
+
+// ---- reference layout <-> wave chunks ------------------------------------------------------
+// Reference Body block (ensemble.hpp:131-150), RC = ref chunk: doubles
+//   [x_pos RC][x_vel RC][y_pos RC][y_vel RC][z_pos RC][z_vel RC][mass RC][attr nbattr x RC]
+// system i, body b lives in Body block (i/RC)*nbod + b at lane i%RC (ensemble.hpp:499-517).
+// Reference Sys block (ensemble.hpp:227-238): [time RC doubles][{int state; int id} x RC][attr nsattr x RC].
+// One workgroup of 64 threads converts one wave chunk.  The reference image of those 64 systems
+// is 64/RC contiguous block groups: it is streamed through LDS with fully coalesced loads/stores
+// and transposed there, so neither side sees strided 64-byte segments.
+template <bool IMPORT>
+__global__ __launch_bounds__(64) void ref_layout_kernel(EnsView e, double *ref_body, double *ref_sys, int RC) {
+    extern __shared__ double lds[];
+    const int chunk = blockIdx.x, lane = threadIdx.x;
+    const int n = e.nbod, nbf = e.nbf, nsf = e.nsf;
+    const int groups = W / RC; // reference block groups per wave chunk
+    // ---- bodies: reference doubles for this wave chunk are contiguous
+    const size_t body_doubles = (size_t)n * nbf * W;
+    double *rb = ref_body + (size_t)chunk * body_doubles;
+    double *ob = e.body + (size_t)chunk * body_doubles;
+    // number of valid reference doubles (the last wave chunk may be short on the reference side)
+    const long long nsys_here = min((long long)W, (long long)e.nsys - (long long)chunk * W);
+    const int groups_here = (int)((nsys_here + RC - 1) / RC);
+    const size_t valid = (size_t)groups_here * n * nbf * RC;
+    // reference index r = ((g*n + b)*nbfr + fr)*RC + l  with fr order x_pos,x_vel,y_pos,y_vel,z_pos,z_vel,mass,attr
+    // ours      index o = (b*nbf + f)*W + (g*RC + l)     with f  order x,y,z,vx,vy,vz,mass,attr
+    if (IMPORT) {
+        for (size_t k = lane; k < body_doubles; k += W) lds[k] = (k < valid) ? rb[k] : 0.0;
+        __syncthreads();
+        for (size_t o = lane; o < body_doubles; o += W) {
+            const int sysl = (int)(o % W);
+            const int f = (int)((o / W) % nbf), b = (int)(o / ((size_t)W * nbf));
+            const int g = sysl / RC, l = sysl % RC;
+            const int fr = f < 3 ? 2 * f : (f < 6 ? 2 * (f - 3) + 1 : f);
+            ob[o] = lds[((size_t)(g * n + b) * nbf + fr) * RC + l];
+        }
+    } else {
+        for (size_t o = lane; o < body_doubles; o += W) lds[o] = ob[o];
+        __syncthreads();
+        for (size_t k = lane; k < valid; k += W) {
+            const int l = (int)(k % RC);
+            const int fr = (int)((k / RC) % nbf);
+            const int gb = (int)(k / ((size_t)RC * nbf));
+            const int b = gb % n, g = gb / n;
+            const int f = fr < 6 ? (fr % 2 == 0 ? fr / 2 : 3 + fr / 2) : fr;
+            rb[k] = lds[((size_t)b * nbf + f) * W + g * RC + l];
+        }
+    }
+    __syncthreads();
+    // ---- systems: Sys block = (1 + 1 + nsattr) * RC doubles (the {state,id} pair is 8 bytes)
+    const int sdr = (2 + (nsf - 1)) * RC;
+    double *rs = ref_sys + (size_t)chunk * groups * sdr;
+    const int gidx = chunk * W + lane;
+    if (gidx < e.nsys) {
+        const int g = lane / RC, l = lane % RC;
+        double *blk = rs + (size_t)g * sdr;
+        int32_t *bunch = reinterpret_cast<int32_t *>(blk + RC) + 2 * l;
+        double *od = e.sysd + (size_t)chunk * nsf * W + lane;
+        int32_t *oi = e.sysi + (size_t)chunk * 2 * W + lane;
+        if (IMPORT) {
+            od[0] = blk[l];
+            oi[0] = bunch[0];
+            oi[W] = bunch[1];
+            for (int a = 1; a < nsf; a++) od[(size_t)a * W] = blk[(size_t)(1 + a) * RC + l];
+        } else {
+            blk[l] = od[0];
+            bunch[0] = oi[0];
+            bunch[1] = oi[W];
+            for (int a = 1; a < nsf; a++) blk[(size_t)(1 + a) * RC + l] = od[(size_t)a * W];
+        }
+    } else if (IMPORT) {
+        e.sysd[(size_t)chunk * nsf * W + lane] = 0.0;
+        e.sysi[(size_t)chunk * 2 * W + lane] = SWARM_HIP_DISABLED;
+        e.sysi[(size_t)chunk * 2 * W + W + lane] = -1;
+    }
+}
+
+static int grid_for(int nsys, int block) { return (int)(((long long)nsys + block - 1) / block); }
+
+} // namespace swh
+
+using namespace swh;
+
+// =============================================================================================
+extern "C" {
+
+const char *swarm_hip_last_error(void) { return g_err; }
+const char *swarm_hip_version(void) { return "swarm_hip 0.1 (gfx950)"; }
+
+int swarm_hip_init(int device) {
+    HIP_TRY(hipSetDevice(device));
+    int32_t *s = nullptr;
+    return scratch_for_current(&s);
+}
+
+int64_t swarm_hip_nchunk(int32_t nsys) { return ((int64_t)nsys + W - 1) / W; }
+size_t swarm_hip_body_bytes(int32_t nsys, int32_t nbod, int32_t nbattr) {
+    return (size_t)swarm_hip_nchunk(nsys) * nbod * (7 + nbattr) * W * sizeof(double);
+}
+size_t swarm_hip_sysd_bytes(int32_t nsys, int32_t nsattr) {
+    return (size_t)swarm_hip_nchunk(nsys) * (1 + nsattr) * W * sizeof(double);
+}
+size_t swarm_hip_sysi_bytes(int32_t nsys) { return (size_t)swarm_hip_nchunk(nsys) * 2 * W * sizeof(int32_t); }
+int64_t swarm_hip_snapshot_record_bytes(int32_t nbod) { return (32 + 64 * (int64_t)nbod + 15) / 16 * 16; }
+
+int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip_launch_t *a) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!a) {
+        set_error("launch arguments pointer is NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys == 0) return SWARM_HIP_OK;
+    LaunchCtx c;
+    c.ens = view_of(ens);
+    c.ip.max_iterations = a->max_iterations;
+    c.ip.destination_time = a->destination_time;
+    c.ip.time_step = a->time_step;
+    c.ip.time_step_factor = a->time_step_factor;
+    c.ip.min_time_step = a->min_time_step;
+    c.ip.max_time_step = a->max_time_step;
+    c.ip.error_tolerance = a->error_tolerance;
+    c.ip.max_timestep = a->max_timestep;
+    c.ip.timestep_scale = a->timestep_scale;
+    if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_EJECTION_OR_CLOSE) {
+        set_error("unknown monitor id %d", a->monitor);
+        return SWARM_HIP_EINVAL;
+    }
+    c.mp.kind = a->monitor;
+    c.mp.ej_deactivate = a->deactivate_on_ejection != 0;
+    c.mp.ej_log = a->log_on_ejection != 0;
+    c.mp.ej_any = c.mp.ej_deactivate || c.mp.ej_log || (a->verbose_on_ejection != 0);
+    c.mp.ce_deactivate = a->deactivate_on_close_encounter != 0;
+    c.mp.ce_log = a->log_on_close_encounter != 0;
+    c.mp.ce_any = c.mp.ce_deactivate || c.mp.ce_log || (a->verbose_on_close_encounter != 0);
+    c.mp.rmax = a->rmax;
+    // lower bound of { r2 : sqrt(r2) >= rmax }: a few ulps under rmax^2 (exact test follows on device)
+    c.mp.r2_below = (a->rmax > 0 && a->rmax < 1e150) ? a->rmax * a->rmax * (1.0 - 8 * DBL_EPSILON) : 0.0;
+    c.mp.dmin3 = a->close_approach * a->close_approach * a->close_approach;
+    c.mp.log_interval = a->log_interval;
+    c.lg.buf = a->log.d_buf;
+    c.lg.cursor = a->log.d_cursor;
+    c.lg.cap = a->log.capacity;
+    if (c.lg.buf && !c.lg.cursor) {
+        set_error("log.d_buf given without log.d_cursor");
+        return SWARM_HIP_EINVAL;
+    }
+    c.cnt.accepted = reinterpret_cast<unsigned long long *>(a->d_steps_accepted);
+    c.cnt.attempted = reinterpret_cast<unsigned long long *>(a->d_steps_attempted);
+    c.block = a->block_size > 0 ? a->block_size : 256;
+    if (c.block % W != 0 || c.block > 256) {
+        set_error("block_size=%d must be a multiple of 64 and at most 256", c.block);
+        return SWARM_HIP_EINVAL;
+    }
+    c.grid = grid_for(ens->nsys, c.block);
+    c.stream = (hipStream_t)a->stream;
+
+    switch (a->integrator) {
+    case SWARM_HIP_HERMITE:
+    case SWARM_HIP_EULER:
+    case SWARM_HIP_MIDPOINT:
+    case SWARM_HIP_MVS:
+        if (!(a->time_step > 0)) {
+            set_error("time_step must be > 0 (got %g)", a->time_step);
+            return SWARM_HIP_EINVAL;
+        }
+        break;
+    case SWARM_HIP_RKCK_FIXED:
+    case SWARM_HIP_RKCK_ADAPTIVE:
+        if (!(a->max_time_step > 0) || !(a->error_tolerance > 0)) {
+            set_error("rkck needs max_time_step > 0 and error_tolerance > 0");
+            return SWARM_HIP_EINVAL;
+        }
+        break;
+    case SWARM_HIP_VERLET:
+        if (!(a->max_timestep > 0)) {
+            set_error("verlet needs max_timestep > 0");
+            return SWARM_HIP_EINVAL;
+        }
+        break;
+    default:
+        break;
+    }
+    switch (a->integrator) {
+    case SWARM_HIP_HERMITE:
+        return launch_hermite(c, false);
+    case SWARM_HIP_HERMITE_ADAP:
+        return launch_hermite(c, true);
+    case SWARM_HIP_RKCK_FIXED:
+        return launch_rkck(c, false);
+    case SWARM_HIP_RKCK_ADAPTIVE:
+        return launch_rkck(c, true);
+    case SWARM_HIP_MVS:
+    case SWARM_HIP_EULER:
+    case SWARM_HIP_VERLET:
+    case SWARM_HIP_MIDPOINT:
+        return launch_generic(c, a->integrator);
+    default:
+        set_error("unknown integrator id %d", a->integrator);
+        return SWARM_HIP_EINVAL;
+    }
+}
+
+int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_t *count) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!count) {
+        set_error("count pointer is NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    *count = 0;
+    if (ens->nsys == 0) return SWARM_HIP_OK;
+    int32_t *d = nullptr;
+    rc = scratch_for_current(&d);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(count_active_kernel, dim3(grid_for(ens->nsys, 256)), dim3(256), 0, st, view_of(ens), d);
+    rc = check_launch("count_active kernel launch");
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(count, d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SWARM_HIP_OK;
+}
+
+int swarm_hip_reactivate(const swarm_hip_ensemble_t *ens, void *stream) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (ens->nsys == 0) return SWARM_HIP_OK;
+    hipLaunchKernelGGL(reactivate_kernel, dim3(grid_for(ens->nsys, 256)), dim3(256), 0, (hipStream_t)stream,
+                       view_of(ens));
+    return check_launch("reactivate kernel launch");
+}
+
+int swarm_hip_total_energy(const swarm_hip_ensemble_t *ens, double *d_energy, void *stream) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!d_energy) {
+        set_error("d_energy is NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys == 0) return SWARM_HIP_OK;
+    hipLaunchKernelGGL(energy_kernel, dim3(grid_for(ens->nsys, 256)), dim3(256), 0, (hipStream_t)stream,
+                       view_of(ens), d_energy);
+    return check_launch("energy kernel launch");
+}
+
+int swarm_hip_energy_stats(const swarm_hip_ensemble_t *ens, const double *d_e0, const double *d_e1,
+                           double *d_out, void *stream) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!d_e0 || !d_e1 || !d_out) {
+        set_error("energy_stats: NULL device pointer");
+        return SWARM_HIP_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(1), 0, st, d_out, ens->nsys);
+    if (ens->nsys > 0)
+        hipLaunchKernelGGL(stats_kernel, dim3(grid_for(ens->nsys, 256)), dim3(256), 0, st, view_of(ens), d_e0, d_e1,
+                           d_out);
+    return check_launch("stats kernel launch");
+}
+
+static int ref_layout(const swarm_hip_ensemble_t *ens, void *d_ref_body, void *d_ref_sys, int32_t ref_chunk,
+                      void *stream, bool import) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!d_ref_body || !d_ref_sys) {
+        set_error("reference layout pointers must not be NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (ref_chunk < 1 || ref_chunk > W || (W % ref_chunk) != 0) {
+        set_error("ref_chunk=%d must divide %d", ref_chunk, W);
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys == 0) return SWARM_HIP_OK;
+    const int nchunk = (int)swarm_hip_nchunk(ens->nsys);
+    const size_t lds = (size_t)ens->nbod * (7 + ens->nbattr) * W * sizeof(double);
+    if (lds > 160 * 1024) {
+        set_error("wave chunk of %zu bytes does not fit in LDS", lds);
+        return SWARM_HIP_EUNSUPPORTED;
+    }
+    EnsView v = view_of(ens);
+    if (import) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ref_layout_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ref_layout_kernel<true>, dim3(nchunk), dim3(W), lds, (hipStream_t)stream, v,
+                           (double *)d_ref_body, (double *)d_ref_sys, (int)ref_chunk);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ref_layout_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ref_layout_kernel<false>, dim3(nchunk), dim3(W), lds, (hipStream_t)stream, v,
+                           (double *)d_ref_body, (double *)d_ref_sys, (int)ref_chunk);
+    }
+    return check_launch("ref layout kernel launch");
+}
+
+int swarm_hip_import_ref_layout(const swarm_hip_ensemble_t *ens, const void *d_ref_body, const void *d_ref_sys,
+                                int32_t ref_chunk, void *stream) {
+    return ref_layout(ens, const_cast<void *>(d_ref_body), const_cast<void *>(d_ref_sys), ref_chunk, stream, true);
+}
+int swarm_hip_export_ref_layout(const swarm_hip_ensemble_t *ens, void *d_ref_body, void *d_ref_sys,
+                                int32_t ref_chunk, void *stream) {
+    return ref_layout(ens, d_ref_body, d_ref_sys, ref_chunk, stream, false);
+}
+
+// ---- host AoS <-> device wave chunks ---------------------------------------------------------
+int swarm_hip_upload_aos(const swarm_hip_ensemble_t *ens, const double *pos, const double *vel, const double *mass,
+                         const double *time, const int32_t *state, const int32_t *id, const double *body_attr,
+                         const double *sys_attr) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!pos || !vel || !mass || !time || !state || !id) {
+        set_error("upload_aos: NULL host array");
+        return SWARM_HIP_EINVAL;
+    }
+    const int nsys = ens->nsys, n = ens->nbod, nbf = 7 + ens->nbattr, nsf = 1 + ens->nsattr;
+    const size_t nchunk = (size_t)swarm_hip_nchunk(nsys);
+    std::vector<double> hb(nchunk * n * nbf * W, 0.0), hd(nchunk * nsf * W, 0.0);
+    std::vector<int32_t> hi(nchunk * 2 * W, 0);
+    for (size_t k = 0; k < nchunk; k++)
+        for (int l = 0; l < W; l++) {
+            hi[k * 2 * W + l] = SWARM_HIP_DISABLED;
+            hi[k * 2 * W + W + l] = -1;
+        }
+    for (int i = 0; i < nsys; i++) {
+        const size_t k = i / W, l = i % W;
+        for (int b = 0; b < n; b++) {
+            double *r = &hb[((k * n + b) * nbf) * W + l];
+            for (int c = 0; c < 3; c++) {
+                r[c * W] = pos[((size_t)i * n + b) * 3 + c];
+                r[(3 + c) * W] = vel[((size_t)i * n + b) * 3 + c];
+            }
+            r[6 * W] = mass[(size_t)i * n + b];
+            for (int a = 0; a < ens->nbattr; a++)
+                r[(7 + a) * W] = body_attr ? body_attr[((size_t)i * n + b) * ens->nbattr + a] : 0.0;
+        }
+        hd[k * nsf * W + l] = time[i];
+        for (int a = 0; a < ens->nsattr; a++)
+            hd[(k * nsf + 1 + a) * W + l] = sys_attr ? sys_attr[(size_t)i * ens->nsattr + a] : 0.0;
+        hi[k * 2 * W + l] = state[i];
+        hi[k * 2 * W + W + l] = id[i];
+    }
+    if (nsys == 0) return SWARM_HIP_OK;
+    HIP_TRY(hipMemcpy(ens->body, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ens->sysd, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ens->sysi, hi.data(), hi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return SWARM_HIP_OK;
+}
+
+int swarm_hip_download_aos(const swarm_hip_ensemble_t *ens, double *pos, double *vel, double *mass, double *time,
+                           int32_t *state, int32_t *id, double *body_attr, double *sys_attr) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    const int nsys = ens->nsys, n = ens->nbod, nbf = 7 + ens->nbattr, nsf = 1 + ens->nsattr;
+    if (nsys == 0) return SWARM_HIP_OK;
+    const size_t nchunk = (size_t)swarm_hip_nchunk(nsys);
+    std::vector<double> hb(nchunk * n * nbf * W), hd(nchunk * nsf * W);
+    std::vector<int32_t> hi(nchunk * 2 * W);
+    HIP_TRY(hipMemcpy(hb.data(), ens->body, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hd.data(), ens->sysd, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hi.data(), ens->sysi, hi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nsys; i++) {
+        const size_t k = i / W, l = i % W;
+        for (int b = 0; b < n; b++) {
+            const double *r = &hb[((k * n + b) * nbf) * W + l];
+            for (int c = 0; c < 3; c++) {
+                if (pos) pos[((size_t)i * n + b) * 3 + c] = r[c * W];
+                if (vel) vel[((size_t)i * n + b) * 3 + c] = r[(3 + c) * W];
+            }
+            if (mass) mass[(size_t)i * n + b] = r[6 * W];
+            if (body_attr)
+                for (int a = 0; a < ens->nbattr; a++) body_attr[((size_t)i * n + b) * ens->nbattr + a] = r[(7 + a) * W];
+        }
+        if (time) time[i] = hd[k * nsf * W + l];
+        if (sys_attr)
+            for (int a = 0; a < ens->nsattr; a++) sys_attr[(size_t)i * ens->nsattr + a] = hd[(k * nsf + 1 + a) * W + l];
+        if (state) state[i] = hi[k * 2 * W + l];
+        if (id) id[i] = hi[k * 2 * W + W + l];
+    }
+    return SWARM_HIP_OK;
+}
+
+// ---- device memory convenience ---------------------------------------------------------------
+int swarm_hip_malloc(void **d_ptr, size_t bytes) {
+    if (!d_ptr) {
+        set_error("malloc: NULL out pointer");
+        return SWARM_HIP_EINVAL;
+    }
+    *d_ptr = nullptr;
+    if (bytes == 0) return SWARM_HIP_OK;
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_free(void *d_ptr) {
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_memset(void *d_ptr, int value, size_t bytes, void *stream) {
+    if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_memcpy_d2h(void *host, const void *d_ptr, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(host, d_ptr, bytes, hipMemcpyDeviceToHost));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_memcpy_h2d(void *d_ptr, const void *host, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(d_ptr, host, bytes, hipMemcpyHostToDevice));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_event_create(void **event) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    *event = (void *)ev;
+    return SWARM_HIP_OK;
+}
+int swarm_hip_event_record(void *event, void *stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_event_elapsed_ms(void *start, void *stop, float *ms) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_event_destroy(void *event) {
+    HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return SWARM_HIP_OK;
+}
+
+} // extern "C"

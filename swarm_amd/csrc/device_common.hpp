@@ -1,0 +1,357 @@
+// device_common.hpp -- shared device code of libswarm_hip.so (gfx950 only).
+//
+// Design: ONE LANE OWNS ONE SYSTEM.  A wavefront integrates the 64 systems of one "wave chunk";
+// the whole state of a system (positions, velocities, accelerations, jerks, masses, time, state)
+// lives in that lane's VGPRs for every step of the launch, so the reference's per-step global
+// round trips, shared-memory pair tables and __syncthreads (swarm/gpu/gravitation_accjerk.hpp:186-197,
+// SURVEY 3.3) disappear.  HBM is touched once per launch: coalesced 512-byte rows per field.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "swarm_hip.h"
+
+namespace swh {
+
+constexpr int W = SWARM_HIP_CHUNK;
+
+struct EnsView {
+    int nsys, nbod;
+    int nbf; // doubles per body row group: 7 + nbattr
+    int nsf; // 1 + nsattr
+    double *body;
+    double *sysd;
+    int32_t *sysi;
+};
+
+struct MonParams {
+    int kind;
+    int ej_any, ej_deactivate, ej_log;
+    int ce_any, ce_deactivate, ce_log;
+    double rmax;
+    double r2_below; // r2 < r2_below  =>  sqrt(r2) < rmax for certain (host-computed lower bound)
+    double dmin3;    // close_approach^3
+    double log_interval;
+};
+
+struct LogBuf {
+    uint8_t *buf;
+    int32_t *cursor; // [0] bytes used, [1] dropped records
+    int32_t cap;
+};
+
+struct Counters {
+    unsigned long long *accepted;
+    unsigned long long *attempted;
+};
+
+struct IntParams {
+    int max_iterations;
+    double destination_time;
+    double time_step, time_step_factor, min_time_step, max_time_step, error_tolerance;
+    double max_timestep, timestep_scale;
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct State {
+    double p[N][3], v[N][3], m[N];
+    double t;
+    int state, id;
+};
+
+template <int N>
+__device__ __forceinline__ void load_state(const EnsView &e, int gid, State<N> &s) {
+    const int chunk = gid / W, lane = gid % W;
+    const double *b = e.body + (size_t)chunk * N * e.nbf * W + lane;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double *r = b + (size_t)i * e.nbf * W;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            s.p[i][c] = r[c * W];
+            s.v[i][c] = r[(3 + c) * W];
+        }
+        s.m[i] = r[6 * W];
+    }
+    s.t = e.sysd[(size_t)chunk * e.nsf * W + lane];
+    s.state = e.sysi[(size_t)chunk * 2 * W + lane];
+    s.id = e.sysi[(size_t)chunk * 2 * W + W + lane];
+}
+
+template <int N>
+__device__ __forceinline__ void store_state(const EnsView &e, int gid, const State<N> &s) {
+    const int chunk = gid / W, lane = gid % W;
+    double *b = e.body + (size_t)chunk * N * e.nbf * W + lane;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double *r = b + (size_t)i * e.nbf * W;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            r[c * W] = s.p[i][c];
+            r[(3 + c) * W] = s.v[i][c];
+        }
+    }
+    e.sysd[(size_t)chunk * e.nsf * W + lane] = s.t;
+    e.sysi[(size_t)chunk * 2 * W + lane] = s.state;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1/sqrt(x) to double precision: hardware v_rsq_f64 seed + one third-order Newton step.
+// Replaces CUDA rsqrt() in `rsqrt(r2)/r2` (swarm/gpu/gravitation_accjerk.hpp:106).
+__device__ __forceinline__ double rsqrt_full(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double t = x * y;
+    double e = __builtin_fma(-t, y, 1.0);       // 1 - x*y^2
+    double q = __builtin_fma(0.375, e, 0.5);    // 1/2 + 3/8 e
+    return __builtin_fma(y * e, q, y);          // y*(1 + e/2 + 3/8 e^2)
+}
+
+// Pairwise acceleration + jerk, all bodies of one system in registers.
+// Arithmetic follows hermite_cpu::calcForces (integrators/hermite_cpu.hpp:82-110): pairs i<j in
+// lexicographic order, one accumulator per body, scalar = r^-3 * m_other; with
+// r^-3 = rsqrt(r2)^3 and rv = 3 (dx.dv) rsqrt(r2)^2 instead of the reference's two divisions.
+template <int N>
+__device__ __forceinline__ void accjerk(const double (&p)[N][3], const double (&v)[N][3],
+                                        const double (&m)[N], double (&a)[N][3], double (&jk)[N][3]) {
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            const double dx0 = p[j][0] - p[i][0], dx1 = p[j][1] - p[i][1], dx2 = p[j][2] - p[i][2];
+            const double dv0 = v[j][0] - v[i][0], dv1 = v[j][1] - v[i][1], dv2 = v[j][2] - v[i][2];
+            const double r2 = __builtin_fma(dx2, dx2, __builtin_fma(dx1, dx1, dx0 * dx0));
+            const double xv = __builtin_fma(dx2, dv2, __builtin_fma(dx1, dv1, dx0 * dv0));
+            const double y = rsqrt_full(r2);
+            const double y2 = y * y;
+            const double rinv = y * y2;           // r^-3
+            const double rv = (xv * 3.0) * y2;    // 3 (dx.dv) / r2
+            const double si = rinv * m[j];
+            const double sj = -(rinv * m[i]);
+            const double t0 = __builtin_fma(-dx0, rv, dv0), t1 = __builtin_fma(-dx1, rv, dv1),
+                         t2 = __builtin_fma(-dx2, rv, dv2);
+            const bool first_i = (i == 0 && j == 1); // compile-time after unrolling
+            const bool first_j = (i == 0);
+            if (first_i) {
+                a[i][0] = dx0 * si, a[i][1] = dx1 * si, a[i][2] = dx2 * si;
+                jk[i][0] = t0 * si, jk[i][1] = t1 * si, jk[i][2] = t2 * si;
+            } else {
+                a[i][0] = __builtin_fma(dx0, si, a[i][0]);
+                a[i][1] = __builtin_fma(dx1, si, a[i][1]);
+                a[i][2] = __builtin_fma(dx2, si, a[i][2]);
+                jk[i][0] = __builtin_fma(t0, si, jk[i][0]);
+                jk[i][1] = __builtin_fma(t1, si, jk[i][1]);
+                jk[i][2] = __builtin_fma(t2, si, jk[i][2]);
+            }
+            if (first_j) {
+                a[j][0] = dx0 * sj, a[j][1] = dx1 * sj, a[j][2] = dx2 * sj;
+                jk[j][0] = t0 * sj, jk[j][1] = t1 * sj, jk[j][2] = t2 * sj;
+            } else {
+                a[j][0] = __builtin_fma(dx0, sj, a[j][0]);
+                a[j][1] = __builtin_fma(dx1, sj, a[j][1]);
+                a[j][2] = __builtin_fma(dx2, sj, a[j][2]);
+                jk[j][0] = __builtin_fma(t0, sj, jk[j][0]);
+                jk[j][1] = __builtin_fma(t1, sj, jk[j][1]);
+                jk[j][2] = __builtin_fma(t2, sj, jk[j][2]);
+            }
+        }
+    }
+}
+
+// Acceleration only.  Follows GravitationAcc (swarm/gpu/gravitation_acc.hpp:57-74,96-139):
+// `planets_only` skips every pair that touches body 0 (sum_acc_planets, for MVS).
+// r4 (optional) receives |dx * r^-3|^2 per pair = what Verlet's one_over_r() returns (L78-93).
+template <int N, bool PLANETS_ONLY>
+__device__ __forceinline__ void acc_only(const double (&p)[N][3], const double (&m)[N],
+                                         double (&a)[N][3]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i][0] = a[i][1] = a[i][2] = 0.0;
+#pragma unroll
+    for (int i = PLANETS_ONLY ? 1 : 0; i < N - 1; i++) {
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            const double dx0 = p[j][0] - p[i][0], dx1 = p[j][1] - p[i][1], dx2 = p[j][2] - p[i][2];
+            const double r2 = __builtin_fma(dx2, dx2, __builtin_fma(dx1, dx1, dx0 * dx0));
+            const double y = rsqrt_full(r2);
+            const double rinv = y * (y * y);
+            const double si = rinv * m[j];
+            const double sj = -(rinv * m[i]);
+            a[i][0] = __builtin_fma(dx0, si, a[i][0]);
+            a[i][1] = __builtin_fma(dx1, si, a[i][1]);
+            a[i][2] = __builtin_fma(dx2, si, a[i][2]);
+            a[j][0] = __builtin_fma(dx0, sj, a[j][0]);
+            a[j][1] = __builtin_fma(dx1, sj, a[j][1]);
+            a[j][2] = __builtin_fma(dx2, sj, a[j][2]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device event buffer.  Record bytes = reference EVT_SNAPSHOT (swarm/log/log.hpp:313-326,
+// log/types.hpp:37-56, gpulog/bits/gpulog_msg_layout.h:112-204).  The reference reserves with
+// one atomicAdd per record on a single int (bits/gpulog_write.h:14-22); here the lanes of a
+// wavefront that log in the same step reserve together: one atomic per wavefront.
+__device__ __forceinline__ int snapshot_len(int nbod) { return (32 + 64 * nbod + 15) / 16 * 16; }
+
+template <int N>
+__device__ __forceinline__ void log_system(const LogBuf &lg, const State<N> &s, bool want) {
+    const int len = snapshot_len(N);
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    const int cnt = __popcll(mask);
+    int base = 0;
+    if (lane == leader && lg.buf) base = atomicAdd(lg.cursor, cnt * len);
+    base = __shfl(base, leader);
+    if (!want) return;
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const long long off = (long long)base + (long long)rank * len;
+    if (!lg.buf || off + len > (long long)lg.cap) {
+        // overflow: give the bytes back and count the drop (the reference drops silently)
+        if (lg.buf) atomicSub(lg.cursor, len);
+        if (lg.cursor) atomicAdd(lg.cursor + 1, 1);
+        return;
+    }
+    uint8_t *r = lg.buf + off;
+    int32_t *ri = reinterpret_cast<int32_t *>(r);
+    double *rd = reinterpret_cast<double *>(r);
+    ri[0] = 1; // EVT_SNAPSHOT
+    ri[1] = len;
+    rd[1] = s.t;
+    ri[4] = s.id;
+    ri[5] = s.state;
+    ri[6] = N;
+    ri[7] = 0;
+#pragma unroll
+    for (int b = 0; b < N; b++) {
+        double *q = rd + 4 + 8 * b;
+        q[0] = s.p[b][0], q[1] = s.p[b][1], q[2] = s.p[b][2];
+        q[3] = s.v[b][0], q[4] = s.v[b][1], q[5] = s.v[b][2];
+        q[6] = s.m[b];
+        reinterpret_cast<int32_t *>(q + 7)[0] = b;
+        reinterpret_cast<int32_t *>(q + 7)[1] = 0;
+    }
+    for (int k = (32 + 64 * N) / 8; k < len / 8; k++) rd[k] = 0.0; // pad to 16
+}
+
+// ---------------------------------------------------------------------------------------------
+// Monitors.  Every comparison that decides an integer outcome is evaluated without FMA
+// contraction, in the reference's operation order.
+struct MonState {
+    bool ej_met, ce_met;
+    double next_log_time;
+};
+
+template <int N>
+__device__ __forceinline__ void mon_init(MonState &ms, const State<N> &s) {
+    ms.ej_met = false;
+    ms.ce_met = false;
+    ms.next_log_time = s.t; // monitors/log_time_interval.hpp:118-119
+}
+
+// stop_on_ejection::test_body, monitors/stop_on_ejection.hpp:108-138
+template <int N>
+__device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const MonParams &mp) {
+#pragma clang fp contract(off)
+    const double x = s.p[b][0], y = s.p[b][1], z = s.p[b][2];
+    const double r2 = x * x + y * y + z * z;
+    if (r2 < mp.r2_below) return false; // certainly r < rmax; skips the sqrt on the common path
+    const double vx = s.v[b][0], vy = s.v[b][1], vz = s.v[b][2];
+    const double r = sqrt(r2);
+    if (r < mp.rmax) return false;
+    const double rdotv = x * vx + y * vy + z * vz;
+    if (rdotv <= 0.) return false;
+    const double speed_sq = vx * vx + vy * vy + vz * vz;
+    const double epp = 0.5 * speed_sq * r / s.m[b] - 1.;
+    if (fabs(epp) < 1e-4) return true;
+    if (epp > 0) return true;
+    return false;
+}
+
+// stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142
+template <int N>
+__device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp) {
+#pragma clang fp contract(off)
+    const double dx = s.p[i][0] - s.p[j][0], dy = s.p[i][1] - s.p[j][1], dz = s.p[i][2] - s.p[j][2];
+    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+    const double GM = s.m[0];
+    const double ri = sqrt(s.p[i][0] * s.p[i][0] + s.p[i][1] * s.p[i][1] + s.p[i][2] * s.p[i][2]);
+    const double a = 0.5 * (ri + ri); // the reference uses body i twice (L130)
+    const double rH3 = (s.m[i] + s.m[j]) / (3. * GM) * a * a * a;
+    return d * d * d < mp.dmin3 * rH3;
+}
+
+// pass_one of the bound monitor (stop_on_ejection.hpp:177-193, log_time_interval.hpp:98-111,
+// stop_on_close_encounter.hpp:101-115, composites.hpp:199-200).  Returns need_full_test
+// ("this system needs standard coordinates").
+template <int N>
+__device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, const MonParams &mp) {
+    bool need_full = false;
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
+        ms.ej_met = false;
+        if (mp.log_interval != 0.) {
+            if (s.t >= ms.next_log_time) {
+                ms.ej_met = true;
+                ms.next_log_time += mp.log_interval;
+            }
+        }
+        return ms.ej_met;
+    }
+    ms.ej_met = false;
+    if (mp.ej_any) {
+#pragma unroll
+        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body(s, b, mp);
+        if (ms.ej_met && mp.ej_log) need_full = true;
+    }
+    if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && !need_full) { // short-circuit ||
+        ms.ce_met = false;
+        if (mp.ce_any) {
+#pragma unroll
+            for (int b = 2; b < N; b++)
+#pragma unroll
+                for (int d = 1; d < b; d++) ms.ce_met = ms.ce_met || ce_check(s, b, d, mp);
+            if (ms.ce_met && mp.ce_log) need_full = true;
+        }
+    }
+    return need_full;
+}
+
+// pass_two: stop_on_ejection.hpp:196-201, stop_on_close_encounter.hpp:118-123
+template <int N>
+__device__ __forceinline__ void mon_pass_two(const MonState &ms, State<N> &s, const MonParams &mp) {
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) return;
+    if (ms.ej_met && mp.ej_deactivate) s.state = SWARM_HIP_DISABLED;
+    if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && ms.ce_met && mp.ce_deactivate)
+        s.state = SWARM_HIP_DISABLED;
+}
+
+__device__ __forceinline__ bool mon_need_log(const MonState &ms, const MonParams &mp) {
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) return mp.log_interval != 0. && ms.ej_met;
+    bool r = mp.ej_log && ms.ej_met;
+    if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE) r = r || (mp.ce_log && ms.ce_met);
+    return r;
+}
+
+// Monitor::operator()(thread_in_system): pass_one, pass_two, log (stop_on_ejection.hpp:140-146).
+// `participate` = this lane really calls the monitor; all lanes of the wave must reach this
+// function together because log_system reserves space wave-wide.
+template <int N>
+__device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonParams &mp,
+                                         const LogBuf &lg, bool participate) {
+    bool want = false;
+    if (participate) {
+        mon_pass_one(ms, s, mp);
+        mon_pass_two(ms, s, mp);
+        want = mon_need_log(ms, mp);
+    }
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
+        if (__any(want)) log_system(lg, s, want);
+}
+
+__host__ __device__ inline bool monitor_is_noop(const MonParams &mp) {
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) return mp.log_interval == 0.;
+    return !mp.ej_any && !(mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && mp.ce_any);
+}
+
+} // namespace swh

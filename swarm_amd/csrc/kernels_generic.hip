@@ -1,0 +1,368 @@
+// kernels_generic.hip -- propagator kernels: MVS, Euler(3rd-order Taylor), Verlet, Midpoint.
+//
+// Replaces generic<Propagator,Monitor,Gravitation>::kernel
+// (swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238) and the propagators
+// propagators/{mvs,keplerian,euler,verlet,midpoint}.hpp.  One lane per system, state in VGPRs.
+//
+// Deviations from the reference, on purpose:
+//  * the reference converts a whole CUDA block to standard coordinates when ANY system of the
+//    block needs to log (syncthreads_or, L192); here only the system that asked is converted;
+//  * systems that are not ACTIVE at launch are left untouched (the reference runs MVS
+//    init()/shutdown() coordinate round trips on them, which perturbs their last bits).
+#include "launch.hpp"
+
+namespace swh {
+
+// ---- universal-variable Kepler drift: propagators/keplerian.hpp ------------------------------
+// SC_prussing, keplerian.hpp:61-87, including `float absy` and the float sqrt it selects.
+__device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
+    if (fabs(y) < 1e-4) {
+        S = (1.0 / 6.0) * (1.0 - y * (1.0 / 20.0) * (1.0 - y * (1.0 / 42.0) * (1.0 - y * (1.0 / 72.0))));
+        C = (1.0 / 2.0) * (1.0 - y * (1.0 / 12.0) * (1.0 - y * (1.0 / 30.0) * (1.0 - y * (1.0 / 56.0))));
+    } else {
+        float absy = (float)fabs(y);
+        double u = (double)sqrtf(absy);
+        double u3 = u * u * u;
+        if (y > 0.0) {
+            double sn, cs;
+            sincos(u, &sn, &cs);
+            S = (u - sn) / u3;
+            C = (1.0 - cs) / y;
+        } else {
+            S = (sinh(u) - u) / u3;
+            C = (cosh(u) - 1.0) / -y;
+        }
+    }
+}
+
+// solvex, keplerian.hpp:120-159: Laguerre n=5, <= 7 iterations, early exit `i>2 && x+u==x`
+__device__ __forceinline__ double solvex(double r0dotv0, double alpha, double sqrtM1, double r0, double dt) {
+    const double N_LAG = 5.0;
+    const double smu = sqrtM1;
+    const double foo = 1.0 - r0 * alpha;
+    const double sig0 = r0dotv0 / smu;
+    double x = sqrtM1 * sqrtM1 * dt * dt / r0;
+    double u = 1.0;
+    for (int i = 0; (i < 7) && !((i > 2) && (x + u == x)); i++) {
+        const double x2 = x * x, x3 = x2 * x, alx2 = alpha * x2;
+        double Cp, Sp;
+        SC_prussing(alx2, Sp, Cp);
+        const double F = sig0 * x2 * Cp + foo * x3 * Sp + r0 * x - smu * dt;
+        const double dF = sig0 * x * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
+        const double ddF = sig0 * (1.0 - alx2 * Cp) + foo * x * (1.0 - alx2 * Sp);
+        double z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
+        z = sqrt(z);
+        double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
+        if (denom == 0.0) denom = 1e-8;
+        u = N_LAG * F / denom;
+        x -= u;
+    }
+    return x;
+}
+
+// drift_kepler, keplerian.hpp:175-236
+__device__ __forceinline__ void drift_kepler(double (&p)[3], double (&v)[3], const double sqrtGM,
+                                             const double deltaTime) {
+    const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
+    const double r0 = sqrt(x_old * x_old + y_old * y_old + z_old * z_old);
+    const double v2 = (vx_old * vx_old + vy_old * vy_old + vz_old * vz_old);
+    const double r0dotv0 = (x_old * vx_old + y_old * vy_old + z_old * vz_old);
+    const double GM = sqrtGM * sqrtGM;
+    const double alpha = (2.0 / r0 - v2 / GM);
+    const double x_p = solvex(r0dotv0, alpha, sqrtGM, r0, deltaTime);
+    const double smu = sqrtGM;
+    const double foo = 1.0 - r0 * alpha;
+    const double sig0 = r0dotv0 / smu;
+    const double x2 = x_p * x_p, x3 = x2 * x_p, alx2 = alpha * x2;
+    double Cp, Sp;
+    SC_prussing(alx2, Sp, Cp);
+    double r = sig0 * x_p * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
+    if (r < 0.) r = 0.;
+    const double f_p = 1.0 - (x2 / r0) * Cp;
+    const double g_p = deltaTime - (x3 / smu) * Sp;
+    double dfdt;
+    const double dgdt = 1.0 - (x2 / r) * Cp;
+    if (fabs(g_p) > 1e-8)
+        dfdt = (f_p * dgdt - 1.0) / g_p;
+    else
+        dfdt = x_p * smu / (r * r0) * (alx2 * Sp - 1.0);
+    p[0] = f_p * x_old + g_p * vx_old;
+    p[1] = f_p * y_old + g_p * vy_old;
+    p[2] = f_p * z_old + g_p * vz_old;
+    v[0] = dfdt * x_old + dgdt * vx_old;
+    v[1] = dfdt * y_old + dgdt * vy_old;
+    v[2] = dfdt * z_old + dgdt * vz_old;
+}
+
+// ---- MVS coordinate changes: propagators/mvs.hpp:159-190, 195-230 ----------------------------
+template <int N>
+__device__ __forceinline__ void mvs_to_internal(State<N> &s) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double pc0 = s.p[0][c];
+        double sump = 0., sumv = 0., mtot = 0.;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double mj = s.m[j];
+            mtot += mj;
+            sump += mj * s.p[j][c];
+            sumv += mj * s.v[j][c];
+        }
+        sumv /= mtot;
+        s.v[0][c] = sumv;
+        s.p[0][c] = sump / mtot;
+#pragma unroll
+        for (int b = 1; b < N; b++) {
+            s.v[b][c] -= sumv;
+            s.p[b][c] -= pc0;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void mvs_to_std(State<N> &s) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sump = 0., sumv = 0.;
+        const double m0 = s.m[0], pc0 = s.p[0][c], vc0 = s.v[0][c];
+        double mtot = m0;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            const double mj = s.m[j];
+            mtot += mj;
+            sump += mj * s.p[j][c];
+            sumv += mj * s.v[j][c];
+        }
+        sump /= mtot;
+        s.p[0][c] -= sump;
+        s.v[0][c] -= sumv / m0;
+#pragma unroll
+        for (int b = 1; b < N; b++) {
+            s.p[b][c] += pc0 - sump;
+            s.v[b][c] += vc0;
+        }
+    }
+}
+// MVSPropagator::drift_step, mvs.hpp:242-256
+template <int N>
+__device__ __forceinline__ void mvs_drift(State<N> &s, double hby2) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double mv = 0;
+#pragma unroll
+        for (int j = 1; j < N; ++j) mv += s.m[j] * s.v[j][c];
+        s.p[0][c] += hby2 * s.v[0][c];
+#pragma unroll
+        for (int b = 1; b < N; b++) s.p[b][c] += mv * hby2 / s.m[0];
+    }
+}
+
+// Verlet time step: VerletPropagator::calc_timestep (verlet.hpp:112-137) over
+// GravitationAcc::one_over_r (gravitation_acc.hpp:78-93), which returns |dx r^-3|^2 = r^-4.
+template <int N>
+__device__ __forceinline__ double verlet_timestep(const State<N> &s, const IntParams &ip) {
+    double factor = 0.;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            if (i == j) continue;
+            const double dx0 = s.p[j][0] - s.p[i][0], dx1 = s.p[j][1] - s.p[i][1], dx2 = s.p[j][2] - s.p[i][2];
+            const double r2 = dx0 * dx0 + dx1 * dx1 + dx2 * dx2;
+            const double y = rsqrt_full(r2);
+            const double am = y * (y * y);
+            double oor = 0.;
+            oor += (dx0 * am) * (dx0 * am);
+            oor += (dx1 * am) * (dx1 * am);
+            oor += (dx2 * am) * (dx2 * am);
+            factor += (s.m[i] + s.m[j]) * oor * oor * oor;
+        }
+    }
+    factor *= ip.timestep_scale * ip.timestep_scale;
+    factor += 1.;
+    factor = rsqrt_full(factor);
+    factor *= ip.max_timestep;
+    return factor;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int N, int KIND, bool MON>
+__global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
+                                                      Counters cnt) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= e.nsys) return;
+    State<N> s;
+    load_state(e, gid, s);
+    unsigned long long steps = 0;
+    const double dest = ip.destination_time;
+
+    if (s.state == SWARM_HIP_ACTIVE) {
+        MonState ms;
+        mon_init(ms, s);
+        double acc[N][3];
+        double sqrtGM = 0., timestep = 0.;
+        // prop.init()
+        if (KIND == SWARM_HIP_MVS) {
+            sqrtGM = sqrt(s.m[0]);
+            mvs_to_internal(s);
+            acc_only<N, true>(s.p, s.m, acc);
+        } else if (KIND == SWARM_HIP_VERLET) {
+            timestep = verlet_timestep(s, ip);
+        }
+
+        for (int iter = 0; iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; iter++) {
+            double max_timestep;
+            {
+#pragma clang fp contract(off)
+                max_timestep = dest - s.t;
+            }
+            if (KIND == SWARM_HIP_MVS) { // MVSPropagator::advance, mvs.hpp:260-293
+                const double hby2 = 0.5 * fmin(max_timestep, ip.time_step);
+                mvs_drift(s, hby2);
+#pragma unroll
+                for (int b = 1; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
+#pragma unroll
+                for (int b = 1; b < N; b++) drift_kepler(s.p[b], s.v[b], sqrtGM, 2.0 * hby2);
+                acc_only<N, true>(s.p, s.m, acc);
+#pragma unroll
+                for (int b = 1; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
+                mvs_drift(s, hby2);
+                s.t += 2.0 * hby2;
+            } else if (KIND == SWARM_HIP_EULER) { // EulerPropagator::advance, euler.hpp:101-122
+                const double h = fmin(ip.time_step, max_timestep);
+                const double third = 1.0 / 3.0;
+                double jerk[N][3];
+                accjerk<N>(s.p, s.v, s.m, acc, jerk);
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const double pos = s.p[b][c], vel = s.v[b][c];
+                        s.p[b][c] = pos + h * (vel + (h * 0.5) * (acc[b][c] + (h * third) * jerk[b][c]));
+                        s.v[b][c] = vel + h * (acc[b][c] + (h * 0.5) * jerk[b][c]);
+                    }
+                s.t += h;
+            } else if (KIND == SWARM_HIP_VERLET) { // VerletPropagator::advance, verlet.hpp:139-175
+                const double h = timestep;
+                const double h_first_half = 0.5 * h;
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s.p[b][c] = s.p[b][c] + h_first_half * s.v[b][c];
+                acc_only<N, false>(s.p, s.m, acc);
+                timestep = verlet_timestep(s, ip);
+                const double h_second_half = 0.5 * timestep;
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        double vel = s.v[b][c] + h_first_half * acc[b][c];
+                        vel = vel + h_second_half * acc[b][c];
+                        s.v[b][c] = vel;
+                        s.p[b][c] = s.p[b][c] + h_second_half * vel;
+                    }
+                s.t += h_first_half + h_second_half;
+            } else { // MidpointPropagator::advance, midpoint.hpp:106-160
+                const double H = fmin(max_timestep, ip.time_step);
+                const int n = 4;
+                const double h = H / n;
+                double p_i[N][3], p_im1[N][3], p_im2[N][3], v_i[N][3], v_im1[N][3], v_im2[N][3];
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) p_im1[b][c] = s.p[b][c], v_im1[b][c] = s.v[b][c];
+                acc_only<N, false>(p_im1, s.m, acc);
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        p_i[b][c] = p_im1[b][c] + h * v_im1[b][c];
+                        v_i[b][c] = v_im1[b][c] + h * acc[b][c];
+                    }
+#pragma unroll
+                for (int i = 2; i <= n; i++) {
+#pragma unroll
+                    for (int b = 0; b < N; b++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            p_im2[b][c] = p_im1[b][c], p_im1[b][c] = p_i[b][c];
+                            v_im2[b][c] = v_im1[b][c], v_im1[b][c] = v_i[b][c];
+                        }
+                    acc_only<N, false>(p_im1, s.m, acc);
+#pragma unroll
+                    for (int b = 0; b < N; b++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            p_i[b][c] = p_im2[b][c] + 2.0 * h * v_im1[b][c];
+                            v_i[b][c] = v_im2[b][c] + 2.0 * h * acc[b][c];
+                        }
+                }
+                acc_only<N, false>(p_i, s.m, acc);
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        s.p[b][c] = 0.5 * (p_i[b][c] + p_im1[b][c] + h * v_i[b][c]);
+                        s.v[b][c] = 0.5 * (v_i[b][c] + v_im1[b][c] + h * acc[b][c]);
+                    }
+                s.t += H;
+            }
+            steps++;
+
+            // monitor (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
+            // standard coordinates only for a system that is about to be logged.
+            if (MON) {
+                const bool needs_std = mon_pass_one(ms, s, mp);
+                if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
+                mon_pass_two(ms, s, mp);
+                const bool want = mon_need_log(ms, mp);
+                if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
+                    if (__any(want)) log_system(lg, s, want);
+                if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_internal(s);
+            }
+            if (s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
+        }
+        // prop.shutdown()
+        if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
+        store_state(e, gid, s);
+    }
+    if (cnt.accepted) cnt.accepted[gid] += steps;
+    if (cnt.attempted) cnt.attempted[gid] += steps;
+}
+
+template <int N, int KIND>
+static int launch_n(const LaunchCtx &c) {
+    if (monitor_is_noop(c.mp))
+        hipLaunchKernelGGL((generic_kernel<N, KIND, false>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
+                           c.ip, c.mp, c.lg, c.cnt);
+    else
+        hipLaunchKernelGGL((generic_kernel<N, KIND, true>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
+                           c.ip, c.mp, c.lg, c.cnt);
+    return check_launch("propagator kernel launch");
+}
+
+int launch_generic(const LaunchCtx &c, int integrator) {
+    switch (integrator) {
+    case SWARM_HIP_MVS:
+        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
+        break;
+    case SWARM_HIP_EULER:
+        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_EULER>(c)));
+        break;
+    case SWARM_HIP_VERLET:
+        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_VERLET>(c)));
+        break;
+    case SWARM_HIP_MIDPOINT:
+        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MIDPOINT>(c)));
+        break;
+    default:
+        set_error("unknown propagator id %d", integrator);
+        return SWARM_HIP_EINVAL;
+    }
+    return SWARM_HIP_OK;
+}
+
+} // namespace swh

@@ -1,0 +1,50 @@
+// launch.hpp -- host-side glue shared by the kernel translation units of libswarm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_common.hpp"
+
+namespace swh {
+
+struct LaunchCtx {
+    EnsView ens;
+    IntParams ip;
+    MonParams mp;
+    LogBuf lg;
+    Counters cnt;
+    int block;      // threads per workgroup
+    int grid;       // workgroups
+    hipStream_t stream;
+};
+
+void set_error(const char *fmt, ...);
+
+// one entry per kernel translation unit; each dispatches on nbod
+int launch_hermite(const LaunchCtx &c, bool adaptive);
+int launch_rkck(const LaunchCtx &c, bool adaptive);
+int launch_generic(const LaunchCtx &c, int integrator);
+
+// nbod -> template dispatch, the analogue of choose<> (swarm/gpu/helpers.hpp:97-107,216-238)
+#define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
+    switch (nbod) {                                                        \
+    case 3: { constexpr int N = 3; CALL; } break;                          \
+    case 4: { constexpr int N = 4; CALL; } break;                          \
+    case 5: { constexpr int N = 5; CALL; } break;                          \
+    case 6: { constexpr int N = 6; CALL; } break;                          \
+    case 7: { constexpr int N = 7; CALL; } break;                          \
+    case 8: { constexpr int N = 8; CALL; } break;                          \
+    default:                                                               \
+        set_error("nbod=%d outside [%d,%d]", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD); \
+        return SWARM_HIP_EINVAL;                                           \
+    }
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SWARM_HIP_EHIP;
+    }
+    return SWARM_HIP_OK;
+}
+
+} // namespace swh

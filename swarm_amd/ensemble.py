@@ -1,0 +1,168 @@
+"""Host and device ensembles.
+
+HostEnsemble mirrors swarm::hostEnsemble's accessors over plain numpy AoS arrays;
+DeviceEnsemble owns the wave-chunk device image (include/swarm_hip.h) -- the counterpart of
+deviceEnsemble / EnsembleAlloc::cloneTo (swarm/ensemble_alloc.hpp:30-68)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class HostEnsemble:
+    def __init__(self, nsys, nbod, nbattr=1, nsattr=1):
+        self.nsys, self.nbod, self.nbattr, self.nsattr = int(nsys), int(nbod), int(nbattr), int(nsattr)
+        self.pos = np.zeros((nsys, nbod, 3))
+        self.vel = np.zeros((nsys, nbod, 3))
+        self.mass = np.zeros((nsys, nbod))
+        self.time = np.zeros(nsys)
+        self.state = np.zeros(nsys, dtype=np.int32)
+        self.id = np.arange(nsys, dtype=np.int32)
+        self.body_attr = np.zeros((nsys, nbod, nbattr))
+        self.sys_attr = np.zeros((nsys, nsattr))
+
+    @staticmethod
+    def create(nbod, nsys):
+        return HostEnsemble(nsys, nbod)
+
+    def clone(self):
+        e = HostEnsemble(self.nsys, self.nbod, self.nbattr, self.nsattr)
+        for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
+            setattr(e, k, getattr(self, k).copy())
+        return e
+
+    def slice(self, lo, hi):
+        e = HostEnsemble(hi - lo, self.nbod, self.nbattr, self.nsattr)
+        for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
+            setattr(e, k, np.ascontiguousarray(getattr(self, k)[lo:hi]))
+        return e
+
+    # swarm/types/ensemble.hpp:402-413 (host twin; the device version is swarm_hip_total_energy)
+    def calc_total_energy(self):
+        K = (0.5 * self.mass * (self.vel ** 2).sum(-1)).sum(-1)
+        U = np.zeros(self.nsys)
+        for i in range(self.nbod):
+            for j in range(i):
+                d = np.sqrt(((self.pos[:, i] - self.pos[:, j]) ** 2).sum(-1))
+                U += -self.mass[:, i] * self.mass[:, j] / d
+        return K + U
+
+
+def generate_ensemble(cfg):
+    """swarm/utils.cpp:63-103 (deterministic in the reference: theta = bod*pi/4)."""
+    nsys, nbod = cfg.require("nsys", 0), cfg.require("nbod", 0)
+    spacing_factor = cfg.optional("spacing_factor", 1.4)
+    planet_mass = cfg.optional("planet_mass", .0001)
+    ejection_factor = cfg.optional("ejection_factor", 1.0 / math.sqrt(2))
+    star_radius = cfg.optional("star_radius", 0.1)
+    planet_radius = cfg.optional("planet_radius", 0.001)
+    e = HostEnsemble(nsys, nbod)
+    e.mass[:, 0] = 1.
+    e.body_attr[:, 0, 0] = star_radius
+    for bod in range(1, nbod):
+        rmag = 10 * math.pow(spacing_factor, int(bod - 1))
+        vmag = math.sqrt(2 * 1. / rmag) * ejection_factor
+        theta = bod * math.pi / 4
+        e.pos[:, bod] = (rmag * math.cos(theta), rmag * math.sin(theta), 0)
+        e.vel[:, bod] = (-vmag * math.sin(theta), vmag * math.cos(theta), 0.)
+        e.mass[:, bod] = planet_mass
+        e.body_attr[:, bod, 0] = planet_radius
+    e.state[:] = capi.ACTIVE
+    e.time[:] = 0
+    e.id[:] = np.arange(nsys)
+    return e
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by this object."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        capi.check(capi.lib.swarm_hip_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value or 0
+
+    def zero(self, stream=None):
+        capi.check(capi.lib.swarm_hip_memset(self.ptr, 0, self.nbytes, stream))
+
+    def to_host(self, dtype=np.uint8, nbytes=None):
+        n = self.nbytes if nbytes is None else int(nbytes)
+        out = np.empty(n, dtype=np.uint8)
+        capi.check(capi.lib.swarm_hip_memcpy_d2h(_ptr(out), self.ptr, n))
+        return out.view(dtype)
+
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        capi.check(capi.lib.swarm_hip_memcpy_h2d(self.ptr, _ptr(arr), arr.nbytes))
+
+    def free(self):
+        if self.ptr:
+            capi.lib.swarm_hip_free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceEnsemble:
+    """Wave-chunk device image.  Buffers are either owned (hipMalloc) or borrowed device
+    pointers (e.g. torch tensors in bench.py)."""
+
+    def __init__(self, nsys, nbod, nbattr=1, nsattr=1, pointers=None):
+        self.nsys, self.nbod, self.nbattr, self.nsattr = int(nsys), int(nbod), int(nbattr), int(nsattr)
+        L = capi.lib
+        self.body_bytes = L.swarm_hip_body_bytes(nsys, nbod, nbattr)
+        self.sysd_bytes = L.swarm_hip_sysd_bytes(nsys, nsattr)
+        self.sysi_bytes = L.swarm_hip_sysi_bytes(nsys)
+        if pointers is None:
+            self._own = [DeviceBuffer(max(self.body_bytes, 8)), DeviceBuffer(max(self.sysd_bytes, 8)),
+                         DeviceBuffer(max(self.sysi_bytes, 8))]
+            pointers = [b.ptr for b in self._own]
+        else:
+            self._own = []
+        self.c = capi.EnsembleStruct(self.nsys, self.nbod, self.nbattr, self.nsattr, *pointers)
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+    def upload(self, h):
+        assert (h.nsys, h.nbod) == (self.nsys, self.nbod)
+        arrs = [np.ascontiguousarray(a) for a in (h.pos, h.vel, h.mass, h.time, h.state, h.id,
+                                                  h.body_attr, h.sys_attr)]
+        assert arrs[4].dtype == np.int32 and arrs[5].dtype == np.int32
+        capi.check(capi.lib.swarm_hip_upload_aos(self.ref, *[_ptr(a) for a in arrs]))
+
+    def download(self, h=None):
+        h = h if h is not None else HostEnsemble(self.nsys, self.nbod, self.nbattr, self.nsattr)
+        capi.check(capi.lib.swarm_hip_download_aos(self.ref, _ptr(h.pos), _ptr(h.vel), _ptr(h.mass),
+                                                   _ptr(h.time), _ptr(h.state), _ptr(h.id),
+                                                   _ptr(h.body_attr), _ptr(h.sys_attr)))
+        return h
+
+    def count_active(self, stream=None):
+        n = C.c_int32()
+        capi.check(capi.lib.swarm_hip_count_active(self.ref, stream, C.byref(n)))
+        return n.value
+
+    def reactivate(self, stream=None):
+        capi.check(capi.lib.swarm_hip_reactivate(self.ref, stream))
+
+    def total_energy(self, stream=None):
+        n = capi.lib.swarm_hip_nchunk(self.nsys) * capi.CHUNK
+        buf = DeviceBuffer(max(8 * n, 8))
+        capi.check(capi.lib.swarm_hip_total_energy(self.ref, buf.ptr, stream))
+        capi.check(capi.lib.swarm_hip_synchronize(stream))
+        return buf.to_host(np.float64)[: self.nsys].copy()

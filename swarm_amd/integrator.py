@@ -1,0 +1,245 @@
+"""Host side of the integrator path, mirroring the reference's operator surface:
+
+  swarm::plugin registry          swarm/plugin.{hpp,cpp}          -> PLUGINS / plugin_not_found
+  swarm::integrator::create(cfg)  swarm/integrator.cpp:129-145    -> Integrator.create(cfg)
+  gpu::integrator                 swarm/integrator.{hpp,cpp}      -> GpuIntegrator
+  log::manager                    swarm/log/logmanager.{hpp,cpp}  -> LogManager
+
+Every GPU plugin's launch_integrator() is ONE call of swarm_hip_launch_integrator()."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .config import config, key_not_found  # noqa: F401
+from .ensemble import FLT_MAX, DeviceBuffer, DeviceEnsemble, HostEnsemble
+
+
+class plugin_not_found(RuntimeError):
+    """swarm/plugin.hpp:187-196"""
+
+
+class runtime_error(RuntimeError):
+    """swarm::runtime_error via ERROR(), swarm/runtime_error.hpp:38-51"""
+
+
+# plugin id -> (C-ABI integrator, C-ABI monitor); names as registered in src/plugins/*.cu.
+# `hermite` is bound to mce_stat in this fork (plugins/hermite.cu:40); it ships here with the
+# stop_on_ejection monitor that hermite_cpu -- the parity oracle -- uses.
+PLUGINS = {
+    "integrator_hermite": (capi.HERMITE, capi.MON_EJECTION),
+    "integrator_hermite_adap": (capi.HERMITE_ADAP, capi.MON_EJECTION),
+    "integrator_hermite_adap_log": (capi.HERMITE_ADAP, capi.MON_LOG_INTERVAL),
+    "integrator_hermite_adap_close_encounter": (capi.HERMITE_ADAP, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_rkck_fixed": (capi.RKCK_FIXED, capi.MON_EJECTION),
+    "integrator_rkck_fixed_close_encounter": (capi.RKCK_FIXED, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_rkck_adaptive": (capi.RKCK_ADAPTIVE, capi.MON_EJECTION),
+    "integrator_rkck_adaptive_close_encounter": (capi.RKCK_ADAPTIVE, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_mvs": (capi.MVS, capi.MON_EJECTION),
+    "integrator_mvs_close_encounter": (capi.MVS, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_euler": (capi.EULER, capi.MON_EJECTION),
+    "integrator_verlet": (capi.VERLET, capi.MON_EJECTION),
+    "integrator_midpoint": (capi.MIDPOINT, capi.MON_EJECTION),
+}
+
+
+class LogManager:
+    """log::manager (swarm/log/logmanager.cpp:50-87): owns the device event buffer; flush() copies
+    the used bytes to the host and clears the device cursor.  The default log has 0-byte buffers
+    and a null writer (logmanager.cpp:37-47)."""
+
+    def __init__(self, device_bytes=0, writer=None):
+        self.capacity = int(device_bytes)
+        self.writer = writer  # callable(bytes) or None (= null writer)
+        self.buf = DeviceBuffer(self.capacity) if self.capacity else None
+        self.cursor = DeviceBuffer(8) if self.capacity else None
+        if self.cursor:
+            self.cursor.zero()
+        self.host = bytearray()
+        self.dropped = 0
+
+    @staticmethod
+    def from_config(cfg, device_bytes=50 << 20):
+        """manager::init(cfg, host_sz, dev_sz), logmanager.cpp:50-58; `log_writer` selects the sink"""
+        w = cfg.optional("log_writer", "null")
+        if w == "null":
+            return LogManager(device_bytes, None)
+        if w == "host_array":
+            return LogManager(device_bytes, "host")
+        if w == "binary":
+            from .writers import BinaryWriter
+            return LogManager(device_bytes, BinaryWriter(cfg))
+        raise plugin_not_found("writer_" + w)
+
+    def struct(self):
+        if not self.capacity:
+            return capi.LogStruct(None, None, 0)
+        return capi.LogStruct(self.buf.ptr, self.cursor.ptr, self.capacity)
+
+    def flush(self):
+        if not self.capacity:
+            return
+        cur = self.cursor.to_host(np.int32)
+        used, dropped = int(cur[0]), int(cur[1])
+        self.dropped += dropped
+        if used:
+            raw = self.buf.to_host(np.uint8, used).tobytes()
+            if self.writer == "host":
+                self.host += raw
+            elif self.writer is not None:
+                self.writer.process(raw)
+        self.cursor.zero()
+
+
+class Integrator:
+    """swarm::integrator surface (swarm/integrator.hpp:49-149)."""
+
+    _default_max_iterations = 10000000
+    _default_max_attempts = 1000000
+
+    @staticmethod
+    def create(cfg):
+        if "integrator" not in cfg:
+            raise runtime_error("Integrator type has to be chosen with 'integrator=xxx' keyword")
+        name = cfg["integrator"]
+        if "integrator_" + name not in PLUGINS:
+            raise runtime_error("Integrator " + name + " not found.")
+        return GpuIntegrator(cfg)
+
+
+class GpuIntegrator(Integrator):
+    """gpu::integrator (swarm/integrator.hpp:178-275, integrator.cpp:102-117)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.name = cfg["integrator"]
+        self.int_id, self.mon_id = PLUGINS["integrator_" + self.name]
+        self._max_iterations = cfg.optional("max_iterations", self._default_max_iterations)
+        self._max_attempts = cfg.optional("max_attempts", self._default_max_attempts)
+        self._destination_time = 0.0
+        self._hens = None
+        self._dens = None
+        self._logman = LogManager()
+        self.stream = None
+        a = capi.LaunchStruct()
+        a.integrator, a.monitor = self.int_id, self.mon_id
+        a.block_size = 0
+        spb = cfg.optional("system_per_block", 0)
+        if spb:
+            a.block_size = max(64, min(256, (spb + 63) // 64 * 64))
+        # constructor-time key checks follow each reference ctor
+        if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT):
+            a.time_step = cfg.require("time_step", 0.0)      # hermite_integrator.hpp:44-46 etc.
+        if self.int_id == capi.HERMITE_ADAP:
+            a.time_step_factor = cfg.require("time_step_factor", 0.0)  # hermite_adap.hpp:45-46
+            a.min_time_step = cfg.require("min_time_step", 0.0)
+        if self.int_id in (capi.RKCK_FIXED, capi.RKCK_ADAPTIVE):     # rkck_integrator.hpp:63-71
+            for k, msg in (("min_time_step", "min timestep ('min time step' keyword in the config file)"),
+                           ("max_time_step", "max timestep ('max time step' keyword in the config file)"),
+                           ("error_tolerance", "error tolerance ('error tolerance' keyword in the config file)")):
+                if k not in cfg:
+                    raise runtime_error("Integrator rkck requires a " + msg + ".")
+            a.min_time_step = _atof(cfg["min_time_step"])
+            a.max_time_step = _atof(cfg["max_time_step"])
+            a.error_tolerance = _atof(cfg["error_tolerance"])
+        if self.int_id == capi.VERLET:                                # verlet.hpp:35-39
+            a.max_timestep = cfg.require("max_timestep", 0.0)
+            a.timestep_scale = cfg.require("timestep_scale", 0.0)
+        # monitor params
+        if self.mon_id in (capi.MON_EJECTION, capi.MON_EJECTION_OR_CLOSE):  # stop_on_ejection.hpp:47-53
+            a.rmax = cfg.optional("rmax", FLT_MAX)
+            a.deactivate_on_ejection = int(cfg.optional("deactivate_on_ejection", False))
+            a.log_on_ejection = int(cfg.optional("log_on_ejection", False))
+            a.verbose_on_ejection = int(cfg.optional("verbose_on_ejection", False))
+        if self.mon_id == capi.MON_EJECTION_OR_CLOSE:            # stop_on_close_encounter.hpp:43-49
+            a.close_approach = cfg.optional("close_approach", 0.0)
+            a.deactivate_on_close_encounter = int(cfg.optional("deactivate_on_close_encounter", False))
+            a.log_on_close_encounter = int(cfg.optional("log_on_close_encounter", False))
+            a.verbose_on_close_encounter = int(cfg.optional("verbose_on_close_encounter", False))
+        if self.mon_id == capi.MON_LOG_INTERVAL:                      # log_time_interval.hpp:39-43
+            a.log_interval = cfg.require("log_interval", 0.0)
+        self.args = a
+        self.steps_accepted = None
+        self.steps_attempted = None
+
+    # ---- swarm::integrator API ----
+    def set_ensemble(self, host, device=None):
+        """Shares the caller's host ensemble: results appear in it after integrate()
+        (integrator.hpp:233-236)."""
+        self._hens = host
+        self._dens = device or DeviceEnsemble(host.nsys, host.nbod, host.nbattr, host.nsattr)
+
+    def get_ensemble(self):
+        return self._hens
+
+    def set_destination_time(self, t):
+        self._destination_time = float(t)
+
+    def get_destination_time(self):
+        return self._destination_time
+
+    def set_max_iterations(self, n):
+        self._max_iterations = int(n)
+
+    def set_max_attempts(self, n):
+        self._max_attempts = int(n)
+
+    def set_log_manager(self, lm):
+        self._logman = lm
+
+    def enable_step_counters(self):
+        n = capi.lib.swarm_hip_nchunk(self._dens.nsys) * capi.CHUNK
+        self.steps_accepted = DeviceBuffer(max(8 * n, 8))
+        self.steps_attempted = DeviceBuffer(max(8 * n, 8))
+        self.steps_accepted.zero()
+        self.steps_attempted.zero()
+
+    def step_counts(self):
+        n = self._dens.nsys
+        return (self.steps_accepted.to_host(np.uint64)[:n].copy(),
+                self.steps_attempted.to_host(np.uint64)[:n].copy())
+
+    def upload_ensemble(self):
+        self._dens.upload(self._hens)
+
+    def download_ensemble(self):
+        self._dens.download(self._hens)
+
+    def flush_log(self):
+        self._logman.flush()
+
+    def launch_integrator(self):
+        a = self.args
+        a.destination_time = self._destination_time
+        a.max_iterations = self._max_iterations
+        a.log = self._logman.struct()
+        a.d_steps_accepted = self.steps_accepted.ptr if self.steps_accepted else None
+        a.d_steps_attempted = self.steps_attempted.ptr if self.steps_attempted else None
+        a.stream = self.stream
+        capi.check(capi.lib.swarm_hip_launch_integrator(self._dens.ref, C.byref(a)))
+
+    def core_integrate(self):
+        """The device-resident part of integrate(): attempt loop without host<->device copies."""
+        attempts = 0
+        for _ in range(self._max_attempts):
+            self.launch_integrator()
+            self._logman.flush()
+            attempts += 1
+            if self._dens.count_active(self.stream) == 0:
+                break
+        return attempts
+
+    def integrate(self):
+        """gpu::integrator::integrate, integrator.cpp:102-117"""
+        h = self._hens
+        h.state[h.state == capi.INACTIVE] = capi.ACTIVE  # activate_inactive_systems, L83-89
+        self.upload_ensemble()
+        n = self.core_integrate()
+        self.download_ensemble()
+        return n
+
+
+def _atof(s):
+    from .config import _FLT
+    m = _FLT.match(s)
+    return float(m.group(1)) if m else 0.0

@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """swarm_amd with device 0 selected.  Fails loudly when the HIP extension is missing."""
+    import swarm_amd as S
+    S.capi.check(S.capi.lib.swarm_hip_init(0))
+    return S
+
+
+def to_host(S, e):
+    """oracle.Ensemble -> swarm_amd.HostEnsemble (deep copy)"""
+    h = S.HostEnsemble(e.nsys, e.nbod, e.body_attr.shape[2], e.sys_attr.shape[1])
+    for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
+        setattr(h, k, getattr(e, k).copy())
+    return h
+
+
+def rel_diff(a, b):
+    """max over bodies of |a-b| / max(|b|, tiny): per-body Euclidean, relative to the body's norm"""
+    d = np.sqrt(((a - b) ** 2).sum(-1))
+    n = np.sqrt((b ** 2).sum(-1))
+    return float((d / np.maximum(n, 1e-300)).max())
+
+
+def perturbed(O, nsys, nbod, seed=1, amp=1e-3, **kw):
+    """Generated ensemble with a deterministic per-system perturbation so that systems differ."""
+    e = O.generate(nsys, nbod, **kw)
+    rng = np.random.default_rng(seed)
+    e.pos[:, 1:, :] *= 1.0 + amp * rng.standard_normal((nsys, nbod - 1, 3))
+    e.vel[:, 1:, :] *= 1.0 + amp * rng.standard_normal((nsys, nbod - 1, 3))
+    e.pos[:, 1:, 2] += amp * rng.standard_normal((nsys, nbod - 1))
+    return e

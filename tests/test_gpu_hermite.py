@@ -1,0 +1,148 @@
+"""GPU parity: the HIP Hermite kernels (through the C-ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): integer outcomes (state flags, ids, step counts) and the
+accumulated system time are bit-exact; final positions/velocities agree to 1e-10 relative over a
+short pre-chaotic horizon; relative energy-error distributions match."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, perturbed, rel_diff, to_host
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def run_gpu(S, host, cfg, dest, counters=False):
+    integ = S.Integrator.create(S.config(cfg))
+    integ.set_ensemble(host)
+    integ.set_destination_time(dest)
+    if counters:
+        integ.enable_step_counters()
+    integ.integrate()
+    return integ
+
+
+@pytest.mark.parametrize("nbod", range(3, 9))
+def test_hermite_vs_reference_golden_files(gpu, oracle, nbod):
+    """reference ctest scenario: Hermite.cfg (time_step=0.01) vs test.N.out.txt at 1e-8
+    (cmake/test_integrators.cmake:33-39) -- and vs the oracle's hermite at the same dt at 1e-10"""
+    S, O = gpu, oracle
+    e = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
+    ref = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.out.txt" % nbod))
+    h = to_host(S, e)
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.01"}, 1.0)
+    pd = np.sqrt(((h.pos - ref.pos) ** 2).sum(-1)).max()
+    vd = np.sqrt(((h.vel - ref.vel) ** 2).sum(-1)).max()
+    assert pd < 1e-8 and vd < 1e-8
+    assert (h.state == ref.state).all() and (h.id == ref.id).all()
+    for form in ("hermite", "hermite_cpu"):
+        o = e.clone()
+        O.integrate(o, O.params(form, 1.0, time_step=0.01))
+        assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], o.vel[:, 1:]) < TOL
+        assert np.abs(h.pos[:, 0] - o.pos[:, 0]).max() < TOL and np.abs(h.vel[:, 0] - o.vel[:, 0]).max() < TOL
+        assert (h.time == o.time).all()            # same h sequence -> bit-identical times
+        assert (h.state == o.state).all()
+
+
+@pytest.mark.parametrize("nbod,nsys,dt,T", [(3, 1000, 1e-3, 1.0), (4, 333, 1e-3, 1.0), (6, 129, 1e-3, 0.5),
+                                            (8, 64, 2e-3, 0.5), (3, 65, 1e-4, 1.0)])
+def test_hermite_vs_hermite_cpu_on_perturbed_ensembles(gpu, oracle, nbod, nsys, dt, T):
+    S, O = gpu, oracle
+    e = perturbed(O, nsys, nbod, seed=nbod)
+    e0 = e.clone()
+    h = to_host(S, e)
+    integ = run_gpu(S, h, {"integrator": "hermite", "time_step": repr(dt)}, T, counters=True)
+    acc, att = O.integrate(e, O.params("hermite_cpu", T, time_step=dt), threads=4, counters=True)
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
+    assert np.abs(h.pos[:, 0] - e.pos[:, 0]).max() < TOL
+    assert (h.time == e.time).all() and (h.state == e.state).all() and (h.id == e.id).all()
+    gacc, gatt = integ.step_counts()
+    assert (gacc == acc.astype(np.uint64)).all() and (gatt == att.astype(np.uint64)).all()
+    # energy-error distributions
+    eo = O.energy_error(e, e0)
+    eg = np.abs((h.calc_total_energy() - O.total_energy(e0)) / O.total_energy(e0))
+    assert eg.max() < max(10 * eo.max(), 1e-13)
+    assert abs(np.median(eg) - np.median(eo)) < 1e-13
+
+
+def test_c1_config_cpu_cfg_case(gpu, oracle):
+    """BASELINE configs[0]: samples/CPU.cfg (hermite_cpu dt=1e-4), generated nsys=16 nbod=3, short T"""
+    S, O = gpu, oracle
+    e = O.generate(16, 3)
+    h = to_host(S, e)
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.0001"}, 0.5)
+    O.integrate(e, O.params("hermite_cpu", 0.5, time_step=1e-4))
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
+    assert (h.time == e.time).all() and (h.state == e.state).all()
+
+
+def test_edge_cases_empty_ragged_inactive_and_budget(gpu, oracle):
+    S, O = gpu, oracle
+    # empty ensemble
+    h = S.HostEnsemble(0, 3)
+    assert run_gpu(S, h, {"integrator": "hermite", "time_step": "0.01"}, 1.0) is not None
+    # ragged: nsys not a multiple of 64, mixed initial states and times
+    e = perturbed(O, 131, 3, seed=5)
+    e.state[::7] = O.DISABLED
+    e.state[1::7] = O.INACTIVE          # integrate() re-activates these (integrator.cpp:83-89)
+    e.state[2::7] = O.NEEDS_EXAM        # neither active nor re-activated: must stay untouched
+    e.time[3::7] = 0.25
+    h = to_host(S, e)
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.003"}, 0.9)
+    o = e.clone()
+    O.integrate(o, O.params("hermite_cpu", 0.9, time_step=0.003))
+    assert (h.state == o.state).all() and (h.time == o.time).all()
+    untouched = (e.state == O.DISABLED) | (e.state == O.NEEDS_EXAM)
+    assert (h.pos[untouched] == e.pos[untouched]).all() and (h.vel[untouched] == e.vel[untouched]).all()
+    assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < TOL
+    # iteration budget: max_iterations per launch, re-launch until done (max_attempts loop)
+    e = O.generate(70, 3)
+    h = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "hermite", "time_step": "0.01", "max_iterations": "7"}))
+    integ.set_ensemble(h)
+    integ.set_destination_time(0.3)
+    attempts = integ.integrate()
+    o = e.clone()
+    oattempts = O.integrate(o, O.params("hermite_cpu", 0.3, time_step=0.01, max_iterations=7))
+    assert attempts == oattempts == 5
+    assert (h.time == o.time).all() and rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < TOL
+    # one attempt only: systems stay ACTIVE at the intermediate time
+    h = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "hermite", "time_step": "0.01", "max_iterations": "7",
+                                          "max_attempts": "1"}))
+    integ.set_ensemble(h)
+    integ.set_destination_time(0.3)
+    integ.integrate()
+    o = e.clone()
+    O.integrate(o, O.params("hermite_cpu", 0.3, time_step=0.01, max_iterations=7), max_attempts=1)
+    assert (h.state == O.ACTIVE).all() and (h.time == o.time).all()
+
+
+def test_c2_headline_shape_properties(gpu, oracle):
+    """BASELINE configs[1] at full size: Hermite fixed step, nsys=65536 nbod=3.  The oracle
+    checks a strided sample; size-independent properties cover the rest: all generated systems
+    are identical so every lane must produce bit-identical results, energy is conserved, time
+    reversal returns to the start."""
+    S, O = gpu, oracle
+    nsys = 65536
+    cfg = S.config({"nsys": str(nsys), "nbod": "3"})
+    h = S.generate_ensemble(cfg)
+    h0 = h.clone()
+    integ = run_gpu(S, h, {"integrator": "hermite", "time_step": "0.0001"}, 0.05, counters=True)
+    acc, _ = integ.step_counts()
+    assert (acc == 500).all()
+    assert (h.pos == h.pos[0]).all() and (h.vel == h.vel[0]).all() and (h.time == h.time[0]).all()
+    assert (h.state == 1).all() and (h.id == np.arange(nsys)).all()
+    e = O.generate(4, 3)
+    O.integrate(e, O.params("hermite_cpu", 0.05, time_step=1e-4))
+    assert rel_diff(h.pos[:4, 1:], e.pos[:, 1:]) < TOL and (h.time[:4] == e.time).all()
+    de = np.abs((h.calc_total_energy() - h0.calc_total_energy()) / h0.calc_total_energy())
+    assert de.max() < 1e-13
+    # time reversal: flip velocities, integrate the same span again, flip back
+    h.vel *= -1
+    h.time[:] = 0
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.0001"}, 0.05)
+    h.vel *= -1
+    assert rel_diff(h.pos[:, 1:], h0.pos[:, 1:]) < 1e-12 and rel_diff(h.vel[:, 1:], h0.vel[:, 1:]) < 1e-12

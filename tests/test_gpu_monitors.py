@@ -1,0 +1,140 @@
+"""GPU parity of the fused monitors and the device event buffer: stop flags, ejection events and
+log-record counts must be bit-exact against the oracle; record bytes must decode identically."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, perturbed, rel_diff, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def make(S, cfg, host, dest, log_bytes=0, writer="host"):
+    integ = S.Integrator.create(S.config(cfg))
+    integ.set_ensemble(host)
+    integ.set_destination_time(dest)
+    lm = None
+    if log_bytes:
+        lm = S.LogManager(log_bytes, writer)
+        integ.set_log_manager(lm)
+    integ.integrate()
+    return integ, lm
+
+
+def test_hyperbolic_ejection_fixture_hermite_adap(gpu, oracle):
+    """test/monitors/hyperbolic_orbits/HermiteEjection.cfg -> HermiteEjection.3.out.txt:
+    128/128 systems DISABLED at t ~ 8 with rmax=20"""
+    S, O = gpu, oracle
+    d = os.path.join(GOLDEN, "monitors", "hyperbolic_orbits")
+    e = O.load_text(os.path.join(d, "3.in.txt"))
+    ref = O.load_text(os.path.join(d, "HermiteEjection.3.out.txt"))
+    h = to_host(S, e)
+    cfg = {"integrator": "hermite_adap", "time_step_factor": "0.017", "min_time_step": "0.0000001",
+           "deactivate_on_ejection": "1", "rmax": "20", "system_per_block": "8"}
+    make(S, cfg, h, 100.0)
+    assert (h.state == ref.state).all() and (h.state == O.DISABLED).all()
+    np.testing.assert_allclose(h.time, ref.time, atol=5e-3)
+    o = e.clone()
+    O.integrate(o, O.params("hermite_adap", 100.0, time_step_factor=0.017, min_time_step=1e-7),
+                O.monitor(rmax=20.0, deactivate_on_ejection=1))
+    assert (h.state == o.state).all()
+    np.testing.assert_allclose(h.time, o.time, rtol=1e-9)
+    assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < 1e-9
+
+
+@pytest.mark.parametrize("name,cfg,okw", [
+    ("hermite", {"time_step": "0.01"}, dict(time_step=0.01)),
+    ("mvs", {"time_step": "0.01"}, dict(time_step=0.01)),
+    ("rkck_fixed", {"min_time_step": "0.01", "max_time_step": "0.01", "error_tolerance": "1e-20"},
+     dict(min_time_step=0.01, max_time_step=0.01, error_tolerance=1e-20)),
+    ("euler", {"time_step": "0.01"}, dict(time_step=0.01)),
+])
+def test_ejection_stop_flags_and_stop_times_bit_exact(gpu, oracle, name, cfg, okw):
+    """Fixed-step integrators on hyperbolic planets with per-system speeds: the step at which each
+    system is disabled (its final time) and its flag must equal the oracle's exactly."""
+    S, O = gpu, oracle
+    nsys = 200
+    e = O.generate(nsys, 3, ejection_factor=2.0)
+    f = np.linspace(0.3, 1.6, nsys)[:, None, None]        # bound orbits ... fast escapers
+    e.vel[:, 1:] *= f
+    h = to_host(S, e)
+    c = dict(cfg, integrator=name, deactivate_on_ejection="1", rmax="12.5")
+    make(S, c, h, 6.0)
+    o = e.clone()
+    O.integrate(o, O.params(name, 6.0, **okw), O.monitor(rmax=12.5, deactivate_on_ejection=1))
+    assert (o.state == O.DISABLED).sum() > 20 and (o.state == O.INACTIVE).sum() > 20
+    assert (h.state == o.state).all()
+    assert (h.time == o.time).all()
+    assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < 1e-10
+
+
+def test_log_time_interval_record_counts_and_bytes(gpu, oracle):
+    """hermite_adap_log (C5 path): one record at t0 per launch (monitor runs before the loop,
+    hermite_adap.hpp:130) + one per elapsed log_interval; records byte-compatible."""
+    S, O = gpu, oracle
+    e = O.load_text(os.path.join(GOLDEN, "bdb", "test.4.in.txt"))
+    h = to_host(S, e)
+    cfg = {"integrator": "hermite_adap_log", "time_step_factor": "170e-4", "min_time_step": "0.00001",
+           "log_interval": "0.1"}
+    integ, lm = make(S, cfg, h, 1.0, log_bytes=1 << 20)
+    olog = O.Log(1 << 20)
+    o = e.clone()
+    O.integrate(o, O.params("hermite_adap", 1.0, time_step_factor=170e-4, min_time_step=1e-5),
+                O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), olog)
+    grec, orec = O.parse_log(bytes(lm.host)), olog.records()
+    assert len(grec) == len(orec) and lm.dropped == 0
+    assert all(r["len"] == 288 and r["msgid"] == 1 and r["nbod"] == 4 for r in grec)
+    per_sys_g = np.bincount([r["sys"] for r in grec], minlength=16)
+    per_sys_o = np.bincount([r["sys"] for r in orec], minlength=16)
+    assert (per_sys_g == per_sys_o).all()
+    key = lambda r: (r["sys"], r["time"])
+    for g, w in zip(sorted(grec, key=key), sorted(orec, key=key)):
+        assert g["sys"] == w["sys"] and g["state"] == w["state"]
+        assert abs(g["time"] - w["time"]) <= 1e-9 * max(1.0, abs(w["time"]))
+        assert (g["body_id"] == w["body_id"]).all()
+        np.testing.assert_allclose(g["bodies"], w["bodies"], rtol=1e-9, atol=1e-12)
+    assert (h.state == o.state).all()
+
+
+def test_log_on_ejection_and_overflow_drops(gpu, oracle):
+    """log_on_ejection writes one EVT_SNAPSHOT per ejected system (state already -1 when logged,
+    stop_on_ejection.hpp:140-146); a full buffer drops records instead of corrupting memory
+    (gpulog_write.h:14-22)."""
+    S, O = gpu, oracle
+    nsys = 300
+    e = O.generate(nsys, 3, ejection_factor=2.0)
+    h = to_host(S, e)
+    cfg = {"integrator": "hermite", "time_step": "0.01", "deactivate_on_ejection": "1", "log_on_ejection": "1",
+           "rmax": "12.5"}
+    integ, lm = make(S, cfg, h, 6.0, log_bytes=1 << 20)
+    recs = O.parse_log(bytes(lm.host))
+    assert len(recs) == nsys and sorted(r["sys"] for r in recs) == list(range(nsys))
+    assert all(r["state"] == -1 and r["len"] == 224 for r in recs)
+    assert (h.state == -1).all()
+    for r in recs[:10]:
+        np.testing.assert_array_equal(r["bodies"][:, :3], h.pos[r["sys"]])
+    # overflow: room for 100 records only
+    h = to_host(S, e)
+    integ, lm = make(S, cfg, h, 6.0, log_bytes=100 * 224 + 8)
+    recs = O.parse_log(bytes(lm.host))
+    assert len(recs) == 100 and lm.dropped == nsys - 100
+    assert (h.state == -1).all()
+
+
+def test_close_encounter_composite(gpu, oracle):
+    """hermite_adap_close_encounter = stop_on_ejection_or_close_encounter (composites.hpp:145-222)"""
+    S, O = gpu, oracle
+    e = perturbed(O, 128, 4, seed=9, amp=5e-2, spacing_factor=1.02, planet_mass=1e-3)
+    h = to_host(S, e)
+    cfg = {"integrator": "hermite_adap_close_encounter", "time_step_factor": "0.017", "min_time_step": "1e-7",
+           "deactivate_on_close_encounter": "1", "close_approach": "2.0", "deactivate_on_ejection": "1",
+           "rmax": "30"}
+    make(S, cfg, h, 3.0)
+    o = e.clone()
+    O.integrate(o, O.params("hermite_adap", 3.0, time_step_factor=0.017, min_time_step=1e-7),
+                O.monitor(kind=O.MON_EJECTION_OR_CLOSE, rmax=30.0, deactivate_on_ejection=1,
+                          close_approach=2.0, deactivate_on_close_encounter=1))
+    assert 0 < (o.state == O.DISABLED).sum() < 128
+    assert (h.state == o.state).all()
+    np.testing.assert_allclose(h.time, o.time, rtol=1e-9)
