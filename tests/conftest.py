@@ -52,3 +52,29 @@ def perturbed(O, nsys, nbod, seed=1, amp=1e-3, **kw):
     e.vel[:, 1:, :] *= 1.0 + amp * rng.standard_normal((nsys, nbod - 1, 3))
     e.pos[:, 1:, 2] += amp * rng.standard_normal((nsys, nbod - 1))
     return e
+
+
+def scaled(O, nsys, nbod, lo, hi, seed=3, amp=1e-2, **kw):
+    """Perturbed ensemble whose systems are geometrically scaled copies (size factor lo..hi,
+    velocities / sqrt(factor)): dynamical times differ by (hi/lo)^1.5 across the ensemble, which
+    makes adaptive integrators take very different step counts per system."""
+    e = perturbed(O, nsys, nbod, seed=seed, amp=amp, **kw)
+    s = np.geomspace(lo, hi, nsys)[:, None, None]
+    e.pos *= s
+    e.vel /= np.sqrt(s)
+    return e
+
+
+def head_on(O, nsys, planet_mass=1e-3):
+    """Two planets on (almost) the same circle moving towards each other; the initial angular
+    separation varies per system, so the close-encounter time does too."""
+    e = O.generate(nsys, 3, planet_mass=planet_mass)
+    r = 10.0
+    v = np.sqrt(1 / r)
+    dth = np.linspace(0.2, 1.5, nsys)
+    z = 0 * dth
+    e.pos[:, 1] = np.stack([r + z, z, z], -1)
+    e.vel[:, 1] = np.stack([z, v + z, z], -1)
+    e.pos[:, 2] = np.stack([1.02 * r * np.cos(dth), 1.02 * r * np.sin(dth), z], -1)
+    e.vel[:, 2] = np.stack([v * np.sin(dth), -v * np.cos(dth), z], -1)
+    return e

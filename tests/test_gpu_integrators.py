@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, perturbed, rel_diff, to_host
+from conftest import GOLDEN, perturbed, rel_diff, scaled, to_host
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -97,17 +97,23 @@ def test_reference_ctest_scenarios(gpu, oracle, name, cfg, nbod):
 
 
 def test_c3_rkck_adaptive_nbod6_divergent_steps(gpu, oracle):
-    """BASELINE configs[2] shape: rkck_adaptive, nbod=6, per-system divergent step control.
-    Closely spaced planets make systems take different numbers of attempts."""
+    """BASELINE configs[2] shape: rkck_adaptive, nbod=6, stop_on_ejection monitor armed,
+    per-system divergent step control: the systems' dynamical times span a factor ~190, so
+    accepted-step counts range over ~100..850 with up to ~20 rejected attempts per system."""
     S, O = gpu, oracle
-    e = perturbed(O, 256, 6, seed=3, amp=2e-2, spacing_factor=1.15)
+    e = scaled(O, 256, 6, 0.03, 1.0)
     h = to_host(S, e)
-    cfg = {"min_time_step": "1e-5", "max_time_step": "1e-2", "error_tolerance": "1e-20"}
+    cfg = {"min_time_step": "1e-5", "max_time_step": "0.02", "error_tolerance": "1e-24",
+           "deactivate_on_ejection": "1", "rmax": "500"}
     integ = run_gpu(S, h, "rkck_adaptive", cfg, 2.0)
-    acc, att = O.integrate(e, O.params("rkck_adaptive", 2.0, min_time_step=1e-5, max_time_step=1e-2,
-                                       error_tolerance=1e-20), threads=8, counters=True)
+    acc, att = O.integrate(e, O.params("rkck_adaptive", 2.0, min_time_step=1e-5, max_time_step=0.02,
+                                       error_tolerance=1e-24),
+                           O.monitor(rmax=500.0, deactivate_on_ejection=1), threads=8, counters=True)
     gacc, gatt = integ.step_counts()
-    assert (h.state == e.state).all()
-    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-9
-    assert len(set(acc.tolist())) > 1                      # the workload really is divergent
-    assert np.abs(gatt.astype(np.int64) - att).max() <= 2
+    assert (h.state == e.state).all() and (h.state == O.INACTIVE).all()
+    assert len(set(acc.tolist())) > 50 and (att - acc).max() > 5      # really divergent, really rejecting
+    # step control depends on pow() and on the trajectory to the last bit: counts agree to a few steps
+    assert np.abs(gacc.astype(np.int64) - acc).max() <= 3
+    assert np.abs(gatt.astype(np.int64) - att).max() <= 3
+    np.testing.assert_allclose(h.time, e.time, rtol=1e-12)
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-9 and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < 1e-9
