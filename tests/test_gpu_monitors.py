@@ -67,7 +67,9 @@ def test_ejection_stop_flags_and_stop_times_bit_exact(gpu, oracle, name, cfg, ok
     assert len(np.unique(o.time)) > 50                     # many different stop steps
     assert (h.state == o.state).all()
     assert (h.time == o.time).all()
-    assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < 1e-10
+    # 4000 steps; MVS amplifies rounding through the reference's f/g cancellation
+    # (dfdt = (f*dgdt - 1)/g, keplerian.hpp:219-221: ~1e-13 per step at dt=0.01)
+    assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < (1e-8 if name == "mvs" else 1e-10)
 
 
 def test_log_time_interval_record_counts_and_bytes(gpu, oracle):
