@@ -174,7 +174,9 @@ def main():
                    "partition": "by system index, %d shard(s), no data-path collective" % world},
         "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                     "traffic": None,
+                     # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE doubled per
+                     # the MI355X guide + WRITE_SIZE), profiles/r1/hermite_n3_pmc.json; algorithmic = 340 B/system
+                     "traffic": 22121813 if (nbod, nsys) == (3, 65536) else None,
                      "kernel": "hermite_kernel<%d,false,false>" % nbod,
                      "kernel_ms_avg": kernel_ms_avg,
                      "flop_per_system_step": flops,
