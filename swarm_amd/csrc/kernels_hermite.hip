@@ -8,6 +8,65 @@
 
 namespace swh {
 
+// Per-step constants that depend only on h.  For the fixed-step integrator h changes at most once
+// per launch (the clipped last step), so they are recomputed only when h changes.
+struct StepConsts {
+    double h, hh, h3;        // h, h*0.5, h/3.0             (predictor, hermite_integrator.hpp:131-132)
+    double kp_a, kp_j0, kp_j1; // position corrector weights  (L146)
+    double kv_a, kv_j0, kv_j1; // velocity corrector weights  (L147)
+    __device__ __forceinline__ void set(double h_) {
+        h = h_;
+        hh = h_ * 0.5;
+        h3 = h_ / 3.0;
+        const double h2 = h_ * h_;
+        const double c60 = (1.0 / 60.0) * h_, c12 = (1.0 / 12.0) * h_;
+        // pos = pre + ((0.1-0.25)*(a0-a1) - 1/60*(7 j0 + 2 j1) h) h^2, expanded per operand
+        kp_a = (0.1 - 0.25) * h2;
+        kp_j0 = -(7.0 * c60) * h2;
+        kp_j1 = -(2.0 * c60) * h2;
+        // vel = pre + ((-0.5)*(a0-a1) - 1/12*(5 j0 + j1) h) h
+        kv_a = (-0.5) * h_;
+        kv_j0 = -(5.0 * c12) * h_;
+        kv_j1 = -c12 * h_;
+    }
+};
+
+// One PEC2 Hermite step on register-resident state: predictor, 2 x (force + corrector).
+// (a0,j0) = forces at the start of the step, (a1,j1) receive the forces at the end; the caller
+// alternates the two buffer pairs so no copy `acc0 = acc1` (hermite_integrator.hpp:163) is needed.
+// The corrector is the reference's factored form expanded per operand: the terms in a0,j0 are
+// summed once per step (c0,d0), each round adds the a1,j1 terms and makes ONE rounding at the
+// magnitude of pos/vel, like the reference's final `pre_pos + (...)`.
+template <int N>
+__device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
+                                             const double (&j0)[N][3], double (&a1)[N][3],
+                                             double (&j1)[N][3]) {
+    double pp[N][3], pv[N][3], c0[N][3], d0[N][3];
+#pragma unroll
+    for (int b = 0; b < N; b++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            pp[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[b][c], a0[b][c]), s.v[b][c]),
+                                     s.p[b][c]);
+            pv[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[b][c], a0[b][c]), s.v[b][c]);
+            c0[b][c] = __builtin_fma(k.kp_a, a0[b][c], k.kp_j0 * j0[b][c]);
+            d0[b][c] = __builtin_fma(k.kv_a, a0[b][c], k.kv_j0 * j0[b][c]);
+            s.p[b][c] = pp[b][c];
+            s.v[b][c] = pv[b][c];
+        }
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        accjerk<N>(s.p, s.v, s.m, a1, j1);
+#pragma unroll
+        for (int b = 0; b < N; b++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                s.p[b][c] = pp[b][c] + __builtin_fma(-k.kp_a, a1[b][c], __builtin_fma(k.kp_j1, j1[b][c], c0[b][c]));
+                s.v[b][c] = pv[b][c] + __builtin_fma(-k.kv_a, a1[b][c], __builtin_fma(k.kv_j1, j1[b][c], d0[b][c]));
+            }
+    }
+}
+
 template <int N, bool ADAPTIVE, bool MON>
 __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
@@ -23,21 +82,62 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
     // for every system of the ensemble whatever its state.
     if (ADAPTIVE && MON) mon_call(ms, s, mp, lg, true);
 
-    double a0[N][3], j0[N][3];
     unsigned long long steps = 0;
     if (s.state == SWARM_HIP_ACTIVE) {
-        accjerk<N>(s.p, s.v, s.m, a0, j0);
-
+        double fa[2][N][3], fj[2][N][3]; // ping-pong force buffers
+        accjerk<N>(s.p, s.v, s.m, fa[0], fj[0]);
         const double dest = ip.destination_time;
-        for (int iter = 0; iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; iter++) {
+        StepConsts k;
+        k.set(ip.time_step);
+
+        // everything of a step after h is known: step, time, monitor, end test
+        auto finish_step = [&](const double h, const double (&a0)[N][3], const double (&j0)[N][3],
+                               double (&a1)[N][3], double (&j1)[N][3]) {
+            hermite_step<N>(s, k, a0, j0, a1, j1);
+            s.t += h;
+            steps++;
+            if (MON) mon_call(ms, s, mp, lg, true);
+            if (s.state == SWARM_HIP_ACTIVE) {
+                // end test: hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
+#pragma clang fp contract(off)
+                if (ADAPTIVE ? (s.t >= dest) : (s.t > dest - 1e-12)) s.state = SWARM_HIP_INACTIVE;
+            }
+        };
+
+        int iter = 0;
+        if (!ADAPTIVE) {
+            // Fast path: full steps h = time_step with the constants fixed, two steps per trip
+            // through ping-pong force buffers.  The clipped last step (t + h > dest) and odd
+            // remainders fall through to the general loop below.
+            const double dt = ip.time_step;
+            auto full = [&]() {
+#pragma clang fp contract(off)
+                return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE && !(s.t + dt > dest);
+            };
+            while (full()) {
+                finish_step(dt, fa[0], fj[0], fa[1], fj[1]);
+                iter++;
+                if (full()) {
+                    finish_step(dt, fa[1], fj[1], fa[0], fj[0]);
+                    iter++;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < N; b++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
+                }
+            }
+        }
+        // General loop: per-step h (adaptive step, or the clipped final step of the fixed-step form)
+        while (iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE) {
             double h;
             if (ADAPTIVE) {
                 // calc_adaptive_time_step, hermite_adap.hpp:69-98: sum over bodies of |jerk|^2/|acc|^2
                 double tf = 0.0;
 #pragma unroll
                 for (int b = 0; b < N; b++) {
-                    const double a2 = a0[b][0] * a0[b][0] + a0[b][1] * a0[b][1] + a0[b][2] * a0[b][2];
-                    const double jj = j0[b][0] * j0[b][0] + j0[b][1] * j0[b][1] + j0[b][2] * j0[b][2];
+                    const double a2 = fa[0][b][0] * fa[0][b][0] + fa[0][b][1] * fa[0][b][1] + fa[0][b][2] * fa[0][b][2];
+                    const double jj = fj[0][b][0] * fj[0][b][0] + fj[0][b][1] * fj[0][b][1] + fj[0][b][2] * fj[0][b][2];
                     const double ratio = jj / a2;
                     tf = (b == 0) ? ratio : tf + ratio;
                 }
@@ -49,50 +149,13 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
                 if (s.t + h > dest) h = dest - s.t;
             }
-            const double hh = h * 0.5, h3 = h / 3.0;
-            const double h2 = h * h;
-            const double c60 = (1.0 / 60.0) * h, c12 = (1.0 / 12.0) * h;
-
-            // predict (hermite_integrator.hpp:131-132)
-            double pp[N][3], pv[N][3];
+            k.set(h);
+            finish_step(h, fa[0], fj[0], fa[1], fj[1]);
+            iter++;
 #pragma unroll
             for (int b = 0; b < N; b++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    pp[b][c] = s.p[b][c] + h * (s.v[b][c] + hh * (a0[b][c] + h3 * j0[b][c]));
-                    pv[b][c] = s.v[b][c] + h * (a0[b][c] + hh * j0[b][c]);
-                    s.p[b][c] = pp[b][c];
-                    s.v[b][c] = pv[b][c];
-                }
-
-            // evaluate + correct, twice (hermite_integrator.hpp:137-162, factored form L146-147)
-            double a1[N][3], j1[N][3];
-#pragma unroll
-            for (int round = 0; round < 2; round++) {
-                accjerk<N>(s.p, s.v, s.m, a1, j1);
-#pragma unroll
-                for (int b = 0; b < N; b++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const double da = a0[b][c] - a1[b][c];
-                        s.p[b][c] = pp[b][c] +
-                                    ((0.1 - 0.25) * da - c60 * (7.0 * j0[b][c] + 2.0 * j1[b][c])) * h2;
-                        s.v[b][c] = pv[b][c] + ((-0.5) * da - c12 * (5.0 * j0[b][c] + j1[b][c])) * h;
-                    }
-            }
-#pragma unroll
-            for (int b = 0; b < N; b++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) a0[b][c] = a1[b][c], j0[b][c] = j1[b][c];
-
-            s.t += h;
-            steps++;
-            if (MON) mon_call(ms, s, mp, lg, true);
-            if (s.state == SWARM_HIP_ACTIVE) {
-                // end test: hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
-#pragma clang fp contract(off)
-                if (ADAPTIVE ? (s.t >= dest) : (s.t > dest - 1e-12)) s.state = SWARM_HIP_INACTIVE;
-            }
+                for (int c = 0; c < 3; c++) fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
         }
     }
     if (steps || s.state != state_in) store_state(e, gid, s);
