@@ -1,0 +1,513 @@
+// swarmng.cpp -- implementation of the C++ host mirror (libswarmng_hip.so): plugin registry,
+// integrators over the C-ABI, log manager + writers, snapshot I/O, utils.
+// Reference counterparts are cited per function; nothing here computes trajectories on the CPU.
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "swarm/swarm.h"
+
+int DEBUG_LEVEL = 0;
+
+namespace swarm {
+
+void hipException::check(int rc) {
+    if (rc != 0) throw hipException(std::string("swarm_hip: ") + swarm_hip_last_error());
+}
+
+// ---- plugin registry: swarm/plugin.cpp:28-77 -------------------------------------------------
+typedef std::map<std::string, plugin *> plugins_map_t;
+static plugins_map_t &plugins_map() {
+    static plugins_map_t pmap;
+    return pmap;
+}
+void plugin::add(plugin *p) { plugins_map()[p->id()] = p; }
+plugin *plugin::find(const std::string &name) {
+    plugins_map_t::iterator i = plugins_map().find(name);
+    if (i == plugins_map().end() || i->second == 0) throw plugin_not_found(name);
+    return i->second;
+}
+void *plugin::instance(const std::string &name, const config &cfg) { return plugin::find(name)->create(cfg); }
+std::vector<plugin *> plugin::all() {
+    std::vector<plugin *> v;
+    for (plugins_map_t::iterator i = plugins_map().begin(); i != plugins_map().end(); i++) v.push_back(i->second);
+    return v;
+}
+plugin::help_t plugin::help;
+std::ostream &operator<<(std::ostream &out, const plugin::help_t &) {
+    std::vector<plugin *> ps = plugin::all();
+    out << "Found " << ps.size() << " plugins " << std::endl;
+    for (size_t i = 0; i < ps.size(); i++) out << ps[i]->id() << "\t" << ps[i]->description() << std::endl;
+    return out;
+}
+
+// ---- log -------------------------------------------------------------------------------------
+namespace log {
+
+writer *writer::create(const config &cfg) {
+    std::string name = cfg.optional("log_writer", std::string("null"));
+    std::string plugin_name = "writer_" + name;
+    try {
+        return (writer *)plugin::instance(plugin_name, cfg);
+    } catch (plugin_not_found &e) {
+        ERROR("Log writer " + name + " not found.");
+    }
+}
+
+binary_writer::binary_writer(const config &cfg) {
+    std::string fn = cfg.require("log_output", std::string()) + ".raw";
+    f = fopen(fn.c_str(), "wb");
+    if (!f) ERROR("Could not open '" + fn + "' for writing");
+}
+binary_writer::~binary_writer() { if (f) fclose(f); }
+void binary_writer::process(const char *p, size_t n) { if (n) fwrite(p, 1, n, f); }
+
+static writer_plugin_initializer<null_writer> null_writer_plugin("null", "This is the dummy writer");
+static writer_plugin_initializer<host_array_writer> host_array_writer_plugin("host_array", "Keeps the log in host memory");
+static writer_plugin_initializer<binary_writer> binary_writer_plugin("binary", "Raw gpulog record stream to <log_output>.raw");
+
+manager::~manager() {
+    if (d_buf) swarm_hip_free(d_buf);
+    if (d_cursor) swarm_hip_free(d_cursor);
+}
+void manager::init(const config &cfg, int, int device_buffer_size) {
+    log_writer.reset(writer::create(cfg));
+    if (dynamic_cast<null_writer *>(log_writer.get())) return; // null sink: no device buffer
+    capacity = device_buffer_size;
+    hipErrCheck(swarm_hip_malloc((void **)&d_buf, (size_t)capacity));
+    hipErrCheck(swarm_hip_malloc((void **)&d_cursor, 8));
+    hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));
+    hipErrCheck(swarm_hip_synchronize(0));
+}
+Pmanager &manager::default_log() {
+    static Pmanager lm;
+    if (!lm) {
+        lm.reset(new manager());
+        config cfg;
+        cfg["log_writer"] = "null";
+        lm->init(cfg, 0, 0);
+    }
+    return lm;
+}
+void manager::flush() {
+    if (!d_buf) return;
+    int32_t cur[2] = {0, 0};
+    hipErrCheck(swarm_hip_memcpy_d2h(cur, d_cursor, 8));
+    _dropped += cur[1];
+    if (cur[0] > 0) {
+        host.resize((size_t)cur[0]);
+        hipErrCheck(swarm_hip_memcpy_d2h(host.data(), d_buf, (size_t)cur[0]));
+        log_writer->process((const char *)host.data(), host.size());
+    }
+    if (cur[0] || cur[1]) {
+        hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));
+        hipErrCheck(swarm_hip_synchronize(0));
+    }
+}
+
+} // namespace log
+
+// ---- integrator base: swarm/integrator.cpp ---------------------------------------------------
+const int integrator::_default_max_iterations = 10000000;
+const int integrator::_default_max_attempts = 1000000;
+
+integrator::integrator(const config &cfg) : _destination_time(0) {
+    _logman = log::manager::default_log();
+    _max_iterations = cfg.optional("max_iterations", _default_max_iterations);
+    _max_attempts = cfg.optional("max_attempts", _default_max_attempts);
+}
+int number_of_active_systems(defaultEnsemble ens) {
+    int n = 0;
+    for (int i = 0; i < ens.nsys(); i++)
+        if (ens[i].is_active()) n++;
+    return n;
+}
+int number_of_disabled_systems(defaultEnsemble ens) {
+    int n = 0;
+    for (int i = 0; i < ens.nsys(); i++)
+        if (ens[i].is_disabled()) n++;
+    return n;
+}
+void activate_inactive_systems(defaultEnsemble &ens) {
+    for (int i = 0; i < ens.nsys(); i++)
+        if (ens[i].is_inactive()) ens[i].set_active();
+}
+void integrator::integrate() {
+    activate_inactive_systems(_ens);
+    for (int i = 0; i < _max_attempts; i++) {
+        launch_integrator();
+        _logman->flush();
+        if (number_of_active_systems(_ens) == 0) break;
+    }
+}
+Pintegrator integrator::create(const config &cfg) {
+    Pintegrator integ;
+    if (!cfg.count("integrator")) ERROR("Integrator type has to be chosen with 'integrator=xxx' keyword");
+    std::string name = cfg.at("integrator");
+    std::string plugin_name = "integrator_" + name;
+    try {
+        integ.reset((integrator *)plugin::instance(plugin_name, cfg));
+    } catch (plugin_not_found &e) {
+        ERROR("Integrator " + name + " not found.");
+    }
+    return integ;
+}
+
+// ---- gpu::integrator -------------------------------------------------------------------------
+namespace gpu {
+
+integrator::integrator(const config &cfg) : swarm::integrator(cfg), _stream(0) { std::memset(&_dens, 0, sizeof(_dens)); }
+integrator::~integrator() { release_device(); }
+void integrator::release_device() {
+    if (_dens.body) swarm_hip_free(_dens.body);
+    if (_dens.sysd) swarm_hip_free(_dens.sysd);
+    if (_dens.sysi) swarm_hip_free(_dens.sysi);
+    std::memset(&_dens, 0, sizeof(_dens));
+}
+// integrator.hpp:233-236: clone the host ensemble's shape onto the device
+void integrator::set_ensemble(defaultEnsemble &ens) {
+    _ens = ens;
+    release_device();
+    _dens.nsys = ens.nsys();
+    _dens.nbod = ens.nbod();
+    _dens.nbattr = ensemble::NUM_BODY_ATTRIBUTES;
+    _dens.nsattr = ensemble::NUM_SYS_ATTRIBUTES;
+    if (ens.nsys() == 0) return;
+    hipErrCheck(swarm_hip_malloc((void **)&_dens.body, swarm_hip_body_bytes(_dens.nsys, _dens.nbod, _dens.nbattr)));
+    hipErrCheck(swarm_hip_malloc((void **)&_dens.sysd, swarm_hip_sysd_bytes(_dens.nsys, _dens.nsattr)));
+    hipErrCheck(swarm_hip_malloc((void **)&_dens.sysi, swarm_hip_sysi_bytes(_dens.nsys)));
+}
+void integrator::upload_ensemble() {
+    ensemble::Data &D = _ens.data();
+    hipErrCheck(swarm_hip_upload_aos(&_dens, D.pos.data(), D.vel.data(), D.mass.data(), D.time.data(), D.state.data(),
+                                     D.id.data(), D.battr.data(), D.sattr.data()));
+}
+void integrator::download_ensemble() {
+    ensemble::Data &D = _ens.data();
+    hipErrCheck(swarm_hip_download_aos(&_dens, D.pos.data(), D.vel.data(), D.mass.data(), D.time.data(),
+                                       D.state.data(), D.id.data(), D.battr.data(), D.sattr.data()));
+}
+int integrator::core_integrate() {
+    int attempts = 0;
+    for (int i = 0; i < _max_attempts; i++) {
+        launch_integrator();
+        _logman->flush();
+        attempts++;
+        int32_t n = 0;
+        hipErrCheck(swarm_hip_count_active(&_dens, _stream, &n));
+        if (n == 0) break;
+    }
+    return attempts;
+}
+void integrator::integrate() {
+    activate_inactive_systems(_ens);
+    if (_ens.nsys() == 0) return;
+    upload_ensemble();
+    core_integrate();
+    download_ensemble();
+}
+
+} // namespace gpu
+
+// ---- the plugins: one class, parameterised by kernel and monitor ------------------------------
+// Constructor-time key handling follows each reference constructor (cited inline).
+template <int ID, int MON> class hip_integrator : public gpu::integrator {
+    swarm_hip_launch_t a;
+
+public:
+    hip_integrator(const config &cfg) : gpu::integrator(cfg) {
+        std::memset(&a, 0, sizeof(a));
+        a.integrator = ID;
+        a.monitor = MON;
+        int spb = cfg.optional("system_per_block", 0); // the reference's block-shape knob
+        if (spb > 0) a.block_size = std::max(64, std::min(256, (spb + 63) / 64 * 64));
+        if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_MVS || ID == SWARM_HIP_EULER || ID == SWARM_HIP_MIDPOINT)
+            a.time_step = cfg.require("time_step", 0.0); // hermite_integrator.hpp:44-46, mvs.hpp:41-43, ...
+        if (ID == SWARM_HIP_HERMITE_ADAP) { // hermite_adap.hpp:44-47
+            a.time_step_factor = cfg.require("time_step_factor", 0.0);
+            a.min_time_step = cfg.require("min_time_step", 0.0);
+        }
+        if (ID == SWARM_HIP_RKCK_FIXED || ID == SWARM_HIP_RKCK_ADAPTIVE) { // rkck_integrator.hpp:63-71
+            if (!cfg.count("min_time_step"))
+                ERROR("Integrator rkck requires a min timestep ('min time step' keyword in the config file).");
+            a.min_time_step = atof(cfg.at("min_time_step").c_str());
+            if (!cfg.count("max_time_step"))
+                ERROR("Integrator rkck requires a max timestep ('max time step' keyword in the config file).");
+            a.max_time_step = atof(cfg.at("max_time_step").c_str());
+            if (!cfg.count("error_tolerance"))
+                ERROR("Integrator rkck requires a error tolerance ('error tolerance' keyword in the config file).");
+            a.error_tolerance = atof(cfg.at("error_tolerance").c_str());
+        }
+        if (ID == SWARM_HIP_VERLET) { // verlet.hpp:35-39
+            a.max_timestep = cfg.require("max_timestep", 0.0);
+            a.timestep_scale = cfg.require("timestep_scale", 0.0);
+        }
+        if (MON == SWARM_HIP_MON_EJECTION || MON == SWARM_HIP_MON_EJECTION_OR_CLOSE) { // stop_on_ejection.hpp:47-53
+            a.rmax = cfg.optional("rmax", (double)std::numeric_limits<float>::max());
+            a.deactivate_on_ejection = cfg.optional("deactivate_on_ejection", false);
+            a.log_on_ejection = cfg.optional("log_on_ejection", false);
+            a.verbose_on_ejection = cfg.optional("verbose_on_ejection", false);
+        }
+        if (MON == SWARM_HIP_MON_EJECTION_OR_CLOSE) { // stop_on_close_encounter.hpp:43-49
+            a.close_approach = cfg.optional("close_approach", 0.0);
+            a.deactivate_on_close_encounter = cfg.optional("deactivate_on_close_encounter", false);
+            a.log_on_close_encounter = cfg.optional("log_on_close_encounter", false);
+            a.verbose_on_close_encounter = cfg.optional("verbose_on_close_encounter", false);
+        }
+        if (MON == SWARM_HIP_MON_LOG_INTERVAL) a.log_interval = cfg.require("log_interval", 0.0); // log_time_interval.hpp:41
+    }
+    // = launch_templatized_integrator(this), swarm/gpu/helpers.hpp:216-238: ONE C-ABI call
+    virtual void launch_integrator() {
+        a.destination_time = _destination_time;
+        a.max_iterations = _max_iterations;
+        a.log = _logman->get_gpulog();
+        a.stream = _stream;
+        hipErrCheck(swarm_hip_launch_integrator(&_dens, &a));
+    }
+};
+
+// registry names = src/plugins/*.cu.  `hermite` binds stop_on_ejection here (this fork binds
+// mce_stat, plugins/hermite.cu:40).  hermite_log is commented out in the fork.
+#define REG(var, ID, MON, name, desc) static integrator_plugin_initializer<hip_integrator<ID, MON> > var(name, desc)
+REG(p_hermite, SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION, "hermite", "Hermite PEC2, fixed time step (MI355X)");
+REG(p_hermite_adap, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION, "hermite_adap", "Hermite PEC2, adaptive time step (MI355X)");
+REG(p_hermite_adap_log, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_LOG_INTERVAL, "hermite_adap_log", "hermite_adap + log_time_interval");
+REG(p_hermite_adap_ce, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION_OR_CLOSE, "hermite_adap_close_encounter", "hermite_adap + stop_on_ejection_or_close_encounter");
+REG(p_rkck_fixed, SWARM_HIP_RKCK_FIXED, SWARM_HIP_MON_EJECTION, "rkck_fixed", "Cash-Karp Runge-Kutta, fixed time step (MI355X)");
+REG(p_rkck_fixed_ce, SWARM_HIP_RKCK_FIXED, SWARM_HIP_MON_EJECTION_OR_CLOSE, "rkck_fixed_close_encounter", "rkck_fixed + stop_on_ejection_or_close_encounter");
+REG(p_rkck_adaptive, SWARM_HIP_RKCK_ADAPTIVE, SWARM_HIP_MON_EJECTION, "rkck_adaptive", "Cash-Karp Runge-Kutta, adaptive time step (MI355X)");
+REG(p_rkck_adaptive_ce, SWARM_HIP_RKCK_ADAPTIVE, SWARM_HIP_MON_EJECTION_OR_CLOSE, "rkck_adaptive_close_encounter", "rkck_adaptive + stop_on_ejection_or_close_encounter");
+REG(p_mvs, SWARM_HIP_MVS, SWARM_HIP_MON_EJECTION, "mvs", "This is the integrator based on mvs propagator");
+REG(p_mvs_ce, SWARM_HIP_MVS, SWARM_HIP_MON_EJECTION_OR_CLOSE, "mvs_close_encounter", "This is the integrator based on mvs propagator, monitor stop_on_ejection_or_close_encounter");
+REG(p_euler, SWARM_HIP_EULER, SWARM_HIP_MON_EJECTION, "euler", "This is the integrator based on euler propagator");
+REG(p_verlet, SWARM_HIP_VERLET, SWARM_HIP_MON_EJECTION, "verlet", "This is the integrator based on verlet propagator");
+REG(p_midpoint, SWARM_HIP_MIDPOINT, SWARM_HIP_MON_EJECTION, "midpoint", "This is the integrator based on midpoint propagator");
+
+// ---- swarm::init -----------------------------------------------------------------------------
+void init(const config &cfg) {
+    // select_cuda_device(cfg.optional("CUDA_DEVICE", ...)), swarm.h:49-60; HIP_DEVICE is an alias
+    int dev = cfg.optional("HIP_DEVICE", cfg.optional("CUDA_DEVICE", 0));
+    hipErrCheck(swarm_hip_init(dev));
+    log::manager::default_log()->init(cfg);
+}
+
+// ---- snapshot: swarm/snapshot.cpp ------------------------------------------------------------
+namespace snapshot {
+
+template <class T> static void readfromFILE(FILE *f, T &t, const std::string &fn) {
+    if (fread(&t, 1, sizeof(t), f) != sizeof(t)) throw readfileexception(fn, "File I/O error");
+}
+template <class T> static void writetoFILE(FILE *f, const T &t, const std::string &fn) {
+    if (fwrite(&t, 1, sizeof(t), f) != sizeof(t)) throw writefileexception(fn, "File I/O error");
+}
+
+defaultEnsemble load(const std::string &filename) {
+    FILE *f = fopen(filename.c_str(), "rb");
+    if (!f) throw readfileexception(filename, "cannot open file");
+    header h; sys s; body b;
+    readfromFILE(f, h, filename);
+    if (h.nsysattr > ensemble::NUM_SYS_ATTRIBUTES)
+        throw readfileexception(filename, "The file requires more system attributes than the library can handle");
+    if (h.nbodattr > ensemble::NUM_BODY_ATTRIBUTES)
+        throw readfileexception(filename, "The file requires more planet attributes than the library can handle");
+    hostEnsemble ens = hostEnsemble::create(h.nbod, h.nsys);
+    for (int i = 0; i < h.nsys; i++) {
+        ensemble::SystemRef sr = ens[i];
+        readfromFILE(f, s, filename);
+        sr.id() = s.id, sr.time() = s.time, sr.state() = s.state;
+        for (int l = 0; l < h.nsysattr; l++) sr.attribute(l) = s.attribute[l];
+        for (int j = 0; j < h.nbod; j++) {
+            readfromFILE(f, b, filename);
+            sr[j].mass() = b.mass;
+            for (int c = 0; c < 3; c++) sr[j][c].pos() = b.pos[c], sr[j][c].vel() = b.vel[c];
+            for (int l = 0; l < h.nbodattr; l++) sr[j].attribute(l) = b.attribute[l];
+        }
+    }
+    fclose(f);
+    return ens;
+}
+
+static const char *DEFAULT_IO_TAG = "SwarmDataFile";
+static const int CURRENT_IO_VERSION = 2;
+
+defaultEnsemble load_text(const std::string &filename) {
+    FILE *f = fopen(filename.c_str(), "r");
+    if (!f) throw readfileexception(filename, "cannot open file");
+    header h;
+    char tag[1024];
+    int version = 0;
+    if (fscanf(f, "%1023s %i\n", tag, &version) != 2 || strcmp(DEFAULT_IO_TAG, tag) != 0)
+        throw readfileexception(filename, "Invalid file, header doesn't match");
+    if (version != CURRENT_IO_VERSION) throw readfileexception(filename, "Incorrect version");
+    if (fscanf(f, "%i %i %i %i\n\n\n", &h.nbod, &h.nsys, &h.nsysattr, &h.nbodattr) != 4)
+        throw readfileexception(filename, "Invalid file, header doesn't match");
+    if (h.nsysattr > ensemble::NUM_SYS_ATTRIBUTES)
+        throw readfileexception(filename, "The file requires more system attributes than the library can handle");
+    if (h.nbodattr > ensemble::NUM_BODY_ATTRIBUTES)
+        throw readfileexception(filename, "The file requires more planet attributes than the library can handle");
+    hostEnsemble ens = hostEnsemble::create(h.nbod, h.nsys);
+    int ok = 1;
+    for (int i = 0; i < h.nsys && ok; i++) {
+        ensemble::SystemRef sr = ens[i];
+        ok &= fscanf(f, "%i %le %i\n", &sr.id(), &sr.time(), &sr.state()) == 3;
+        for (int l = 0; l < h.nsysattr; l++) ok &= fscanf(f, "%le ", &sr.attribute(l)) == 1;
+        for (int j = 0; j < h.nbod; j++) {
+            ok &= fscanf(f, "\t%le\n\t%le %le %le\n\t%le %le %le\n\n", &sr[j].mass(), &sr[j][0].pos(), &sr[j][1].pos(),
+                         &sr[j][2].pos(), &sr[j][0].vel(), &sr[j][1].vel(), &sr[j][2].vel()) == 7;
+            for (int l = 0; l < h.nbodattr; l++) ok &= fscanf(f, "%le", &sr[j].attribute(l)) == 1;
+        }
+    }
+    fclose(f);
+    if (!ok) throw readfileexception(filename, "File I/O error");
+    return ens;
+}
+
+void save(defaultEnsemble &ens, const std::string &filename) {
+    FILE *f = fopen(filename.c_str(), "wb");
+    if (!f) throw writefileexception(filename, "cannot open file");
+    header h; sys s; body b;
+    memset(&s, 0, sizeof(s));
+    memset(&b, 0, sizeof(b));
+    h.nsys = ens.nsys(), h.nbod = ens.nbod();
+    h.nsysattr = ensemble::NUM_SYS_ATTRIBUTES, h.nbodattr = ensemble::NUM_BODY_ATTRIBUTES;
+    writetoFILE(f, h, filename);
+    for (int i = 0; i < h.nsys; i++) {
+        ensemble::SystemRef sr = ens[i];
+        s.id = sr.id(), s.time = sr.time(), s.state = sr.state();
+        for (int l = 0; l < h.nsysattr; l++) s.attribute[l] = sr.attribute(l);
+        writetoFILE(f, s, filename);
+        for (int j = 0; j < h.nbod; j++) {
+            for (int c = 0; c < 3; c++) b.pos[c] = sr[j][c].pos(), b.vel[c] = sr[j][c].vel();
+            b.mass = sr[j].mass();
+            for (int l = 0; l < h.nbodattr; l++) b.attribute[l] = sr[j].attribute(l);
+            writetoFILE(f, b, filename);
+        }
+    }
+    fclose(f);
+}
+
+void save_text(defaultEnsemble &ens, const std::string &filename) {
+    FILE *f = fopen(filename.c_str(), "w");
+    if (!f) throw writefileexception(filename, "cannot open file");
+    fprintf(f, "%s %i\n", DEFAULT_IO_TAG, CURRENT_IO_VERSION);
+    fprintf(f, "%i %i %i %i\n\n\n", ens.nbod(), ens.nsys(), ensemble::NUM_SYS_ATTRIBUTES, ensemble::NUM_BODY_ATTRIBUTES);
+    for (int i = 0; i < ens.nsys(); i++) {
+        ensemble::SystemRef sr = ens[i];
+        fprintf(f, "%i %.15le %i\n", sr.id(), sr.time(), sr.state());
+        for (int l = 0; l < ensemble::NUM_SYS_ATTRIBUTES; l++) fprintf(f, "%.15le ", sr.attribute(l));
+        fprintf(f, "\n");
+        for (int j = 0; j < ens.nbod(); j++) {
+            fprintf(f, "\t%.15le\n\t%.15le %.15le %.15le\n\t%.15le %.15le %.15le\n\t", sr[j].mass(), sr[j][0].pos(),
+                    sr[j][1].pos(), sr[j][2].pos(), sr[j][0].vel(), sr[j][1].vel(), sr[j][2].vel());
+            for (int l = 0; l < ensemble::NUM_BODY_ATTRIBUTES; l++) fprintf(f, "%.15le ", sr[j].attribute(l));
+            fprintf(f, "\n\n");
+        }
+        fprintf(f, "\n");
+    }
+    fclose(f);
+}
+
+} // namespace snapshot
+
+// ---- utils: swarm/utils.cpp ------------------------------------------------------------------
+hostEnsemble generate_ensemble(config &cfg) { // utils.cpp:63-103
+    int nsys = cfg.require("nsys", 0);
+    int nbod = cfg.require("nbod", 0);
+    double spacing_factor = cfg.optional("spacing_factor", 1.4);
+    double planet_mass = cfg.optional("planet_mass", .0001);
+    double ejection_factor = cfg.optional("ejection_factor", 1.0 / sqrt(2));
+    double star_radius = cfg.optional("star_radius", 0.1);
+    double planet_radius = cfg.optional("planet_radius", 0.001);
+    hostEnsemble ens = hostEnsemble::create(nbod, nsys);
+    for (int sys = 0; sys < ens.nsys(); ++sys) {
+        double mass_sun = 1.;
+        double x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0;
+        ens.set_body(sys, 0, mass_sun, x, y, z, vx, vy, vz);
+        ens[sys][0].attribute(0) = star_radius;
+        for (int bod = 1; bod < ens.nbod(); ++bod) {
+            double rmag = 10 * pow(spacing_factor, int(bod - 1));
+            double vmag = sqrt(2 * mass_sun / rmag) * ejection_factor;
+            double theta = bod * M_PI / 4; // deterministic in this fork (rand() commented out, L89-90)
+            x = rmag * cos(theta), y = rmag * sin(theta), z = 0;
+            vx = -vmag * sin(theta), vy = vmag * cos(theta), vz = 0.;
+            ens.set_body(sys, bod, planet_mass, x, y, z, vx, vy, vz);
+            ens[sys][bod].attribute(0) = planet_radius;
+        }
+        ens[sys].set_active();
+        ens[sys].time() = 0;
+        ens[sys].id() = sys;
+    }
+    return ens;
+}
+
+double find_max_energy_conservation_error(ensemble &ens, ensemble &reference_ensemble) {
+    return energy_conservation_error_range(ens, reference_ensemble).max;
+}
+ensemble::range_t energy_conservation_error_range(ensemble &ens, ensemble &reference_ensemble) { // utils.cpp:108-121
+    std::vector<double> energy_init(reference_ensemble.nsys()), energy_final(ens.nsys()), deltaE(ens.nsys());
+    reference_ensemble.calc_total_energy(&energy_init[0]);
+    ens.calc_total_energy(&energy_final[0]);
+    for (int sysid = 0; sysid < ens.nsys(); ++sysid)
+        deltaE[sysid] = fabs((energy_final[sysid] - energy_init[sysid]) / energy_init[sysid]);
+    return ensemble::range_t::calculate(deltaE.begin(), deltaE.end());
+}
+
+// utils.cpp:124-138.  The reference rejects nsys > 256000 and nbod > MAX_NBODIES (6 by default);
+// this build accepts what the kernels are instantiated for.
+bool validate_configuration(config &cfg) {
+    bool valid = true;
+    int nsystems = cfg.optional("nsys", 1000);
+    int nbodypersystem = cfg.optional("nbod", 3);
+    if (!(nsystems >= 1) || !(nsystems <= (1 << 24))) valid = false;
+    if (!(nbodypersystem >= SWARM_HIP_MIN_NBOD) || !(nbodypersystem <= SWARM_HIP_MAX_NBOD)) valid = false;
+    return valid;
+}
+
+void outputConfigSummary(std::ostream &o, config &cfg) { // utils.cpp:140-150
+    o << "# Integrator:\t" << cfg["integrator"] << "\n"
+      << "# Time step\t" << cfg["time_step"] << "\n"
+      << "# Destination time\t" << cfg["destination_time"] << "\n"
+      << "# Min time step\t" << cfg["min_time_step"] << "\n"
+      << "# Max time step\t" << cfg["max_time_step"] << "\n"
+      << "# No. Systems\t" << cfg["nsys"] << "\n"
+      << "# No. Bodies\t" << cfg["nbod"] << "\n"
+      << std::endl;
+}
+
+// utils.cpp:154-162 sets integrator=hermite_cpu although docs/swarm_exec.dox:70-77 documents
+// `hermite`; this build has no CPU integrators, so the documented value is used.
+config default_config() {
+    config cfg;
+    cfg["integrator"] = "hermite";
+    cfg["time_step"] = "0.001";
+    cfg["log_writer"] = "null";
+    cfg["nsys"] = "16";
+    cfg["nbod"] = "3";
+    return cfg;
+}
+
+std::ostream &operator<<(std::ostream &o, const ensemble::range_t &r) { // utils.cpp:163-168
+    if (r.min - r.max < 1e-11) return o << r.median;
+    return o << r.median << "[" << (r.min - r.median) << "," << (r.max - r.median) << "] ";
+}
+
+static inline double square(double x) { return x * x; }
+bool compare_ensembles(ensemble &e1, ensemble &e2, double &pos_diff, double &vel_diff, double &time_diff) { // utils.cpp:170-214
+    if (e1.nsys() != e2.nsys() || e1.nbod() != e2.nbod()) return false;
+    pos_diff = vel_diff = time_diff = 0;
+    for (int i = 0; i < e1.nsys(); i++) {
+        for (int j = 0; j < e1.nbod(); j++) {
+            double dp = sqrt(square(e1[i][j][0].pos() - e2[i][j][0].pos()) + square(e1[i][j][1].pos() - e2[i][j][1].pos()) +
+                             square(e1[i][j][2].pos() - e2[i][j][2].pos()));
+            double dv = sqrt(square(e1[i][j][0].vel() - e2[i][j][0].vel()) + square(e1[i][j][1].vel() - e2[i][j][1].vel()) +
+                             square(e1[i][j][2].vel() - e2[i][j][2].vel()));
+            if (dp > pos_diff) pos_diff = dp;
+            if (dv > vel_diff) vel_diff = dv;
+        }
+        double dt = fabs(e1[i].time() - e2[i].time()) / (e1[i].time() + e2[i].time()) * 2;
+        if (dt > time_diff) time_diff = dt;
+    }
+    return true;
+}
+
+} // namespace swarm

@@ -1,0 +1,158 @@
+"""The `swarm` CLI (C++ host mirror over the C-ABI), exercised the way the reference's ctest does
+(cmake/test.cmake, cmake/test_integrators.cmake): every test is a command-line invocation."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+SWARM = os.path.join(ROOT, "swarm_amd", "bin", "swarm")
+INTEG = os.path.join(GOLDEN, "integrators")
+
+
+def run(*args, check=True):
+    p = subprocess.run([SWARM] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    if check:
+        assert p.returncode == 0, (args, p.stdout[-2000:], p.stderr[-2000:])
+    return p
+
+
+# ---------------------------------------------------------------- CPU side (no GPU needed)
+@pytest.mark.parametrize("nbod", [3, 4, 6, 8])
+def test_generate_reproduces_reference_input_files(tmp_path, nbod):
+    """`swarm generate -c generate.cfg nbod=N -O file` (test/integrators/generate.sh) must give the
+    reference's shipped test.N.in.txt byte for byte, except the system-attribute line, which the
+    reference leaves uninitialised (denormals ~9.67e-317 in the shipped files)."""
+    out = tmp_path / "g.txt"
+    run("generate", "nsys=16", "nbod=%d" % nbod, "-O", out)
+    mine = open(out).read().split("\n")
+    ref = open(os.path.join(INTEG, "test.%d.in.txt" % nbod)).read().split("\n")
+    assert len(mine) == len(ref)
+    diff = [i for i, (a, b) in enumerate(zip(mine, ref)) if a != b]
+    # the differing lines are exactly the 16 system-attribute lines: denormal garbage in the reference
+    assert len(diff) == 16
+    assert all(0 < float(ref[i]) < 1e-300 and float(mine[i]) == 0.0 for i in diff), diff[:5]
+
+
+def test_convert_text_binary_roundtrip(tmp_path, oracle):
+    src = os.path.join(INTEG, "test.5.out.txt")
+    b, t = tmp_path / "e.bin", tmp_path / "e.txt"
+    run("convert", "-I", src, "-o", b)
+    run("convert", "-i", b, "-O", t)
+    a, c = oracle.load_text(src), oracle.load_text(str(t))
+    for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr"):
+        assert (getattr(a, k) == getattr(c, k)).all(), k
+    # binary layout: header{4 int} + per system sys{double,int,int,double[1]} + nbod body{double[8]}
+    assert os.path.getsize(b) == 16 + 16 * (24 + 5 * 64)
+
+
+def test_cli_errors_and_plugin_list():
+    p = run("-p")
+    names = [l.split("\t")[0] for l in p.stdout.splitlines()[1:]]
+    for n in ("hermite", "hermite_adap", "hermite_adap_log", "rkck_fixed", "rkck_adaptive", "mvs", "verlet", "euler",
+              "midpoint"):
+        assert "integrator_" + n in names
+    assert {"writer_null", "writer_binary", "writer_host_array"} <= set(names)
+    p = run("generate", "nsys=2", "nbod", check=False)
+    assert p.returncode != 0 and "Wrong parameter value pair : nbod" in p.stderr
+    p = run("integrate", "-c", "/nonexistent.cfg", check=False)
+    assert p.returncode != 0 and "Cannot open configuration file" in p.stderr
+    p = run("--help", check=False)
+    assert p.returncode == 1 and "Possible commands are" in p.stdout
+
+
+# ---------------------------------------------------------------- GPU side
+CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-7)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgid,thr", CTEST)
+@pytest.mark.parametrize("nbod", [3, 4, 5, 6])
+def test_reference_ctest_test_integrator(cfgid, thr, nbod):
+    """cmake/test_integrators.cmake:33-39:
+    swarm test -c <Id>.cfg -I test.N.in.txt -O test.N.out.txt nbod=N destination_time=1
+               pos_threshold=1E-8 vel_threshold=1E-8      (MVS: 1e-7)"""
+    p = run("test", "-c", os.path.join(INTEG, cfgid + ".cfg"), "-I", os.path.join(INTEG, "test.%d.in.txt" % nbod), "-O",
+            os.path.join(INTEG, "test.%d.out.txt" % nbod), "nbod=%d" % nbod, "destination_time=1",
+            "pos_threshold=%g" % thr, "vel_threshold=%g" % thr, "-v", "1")
+    assert "Test success" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgid", ["Hermite", "Hermite_Adaptive", "RKCK_Adaptive", "MVS"])
+def test_reference_ctest_stability(cfgid):
+    """cmake/test_integrators.cmake:42-45: swarm integrate -c <Id>.cfg -d 100 -n 10 nbod=N nsys=16
+    exits 1 if the median |dE/E| exceeds 0.01 (swarm.cpp:61-105)"""
+    p = run("integrate", "-c", os.path.join(INTEG, cfgid + ".cfg"), "-d", 100, "-n", 10, "nbod=4", "nsys=16")
+    lines = p.stdout.strip().splitlines()
+    assert lines[0].startswith("Time, Energy Conservation Factor")
+    rows = [[float(x) for x in l.split(",")] for l in lines[1:]]
+    assert [r[0] for r in rows] == [10.0 * k for k in range(1, 11)]
+    assert all(r[1] < 1e-6 and r[3] == 16 for r in rows)
+
+
+@pytest.mark.gpu
+def test_integrate_defaults_and_failure_modes():
+    run("integrate", "--defaults")                                   # cmake/test.cmake:12
+    p = run("integrate", "--defaults", "--nogpu", check=False)       # cmake/test.cmake:13: no CPU plugins here
+    assert p.returncode != 0 and "no CPU integrators" in p.stderr
+    p = run("integrate", "integrator=hermite_log", "time_step=0.001", "nsys=16", "nbod=3", check=False)
+    assert p.returncode != 0 and "Integrator hermite_log not found." in p.stderr
+    p = run("integrate", "integrator=hermite", "nsys=16", "nbod=3", check=False)
+    assert p.returncode != 0 and "time_step" in p.stderr
+    p = run("integrate", "integrator=hermite", "time_step=0.001", "nsys=16", "nbod=2", check=False)
+    assert p.returncode != 0 and "Invalid configuration" in p.stderr
+
+
+@pytest.mark.gpu
+def test_integrate_text_io_matches_oracle(tmp_path, oracle):
+    """swarm integrate -c Hermite.cfg -I in -O out : the output file equals the oracle's result"""
+    O = oracle
+    out = tmp_path / "o.txt"
+    run("integrate", "-c", os.path.join(INTEG, "Hermite.cfg"), "-I", os.path.join(INTEG, "test.5.in.txt"), "-O", out)
+    got = O.load_text(str(out))
+    e = O.load_text(os.path.join(INTEG, "test.5.in.txt"))
+    O.integrate(e, O.params("hermite_cpu", 1.0, time_step=0.01))
+    pd, vd, td = O.compare(got, e)
+    assert pd < 1e-12 and vd < 1e-13 and td == 0 and (got.state == e.state).all()
+
+
+@pytest.mark.gpu
+def test_benchmark_and_verify_csv():
+    """`make benchmark` = swarm benchmark --range nsys=... -c test/benchmark/Hermite.cfg
+    (cmake/custom.cmake:7-37); CSV columns of swarm.cpp:298-307"""
+    cfg = os.path.join(GOLDEN, "benchmark", "Hermite.cfg")
+    p = run("benchmark", "--range", "nsys=1000,2000", "nbod=3", "-c", cfg, "destination_time=0.1", "-q")
+    lines = [l for l in p.stdout.splitlines() if l.startswith("nsys,")]
+    assert len(lines) == 2
+    f = [x.strip() for x in lines[1].split(",")]
+    assert f[0] == "nsys" and f[1] == "2000" and float(f[2]) == pytest.approx(0.1) and float(f[3]) < 1e-12
+    assert float(f[7]) > 0 and float(f[8]) >= 0
+    assert p.stdout.startswith("Parameter, Value, Time, Energy Conservation Factor (delta E/E)")
+    p = run("verify", "--range", "time_step=0.0001..0.0002..0.0001", "nsys=64", "nbod=3", "integrator=hermite",
+            "time_step=0.0001", "destination_time=0.05", "-q")
+    assert "Verify success" in p.stdout
+    p = run("verify", "--range", "integrator=hermite,euler", "nsys=64", "nbod=3", "integrator=hermite",
+            "time_step=0.01", "destination_time=1", "-q", "pos_threshold=1e-14", check=False)
+    assert p.returncode == 1 and "Verify failed" in p.stderr
+
+
+@pytest.mark.gpu
+def test_log_writers_via_cli(tmp_path, oracle):
+    """hermite_adap_log + log_writer=binary: the raw record stream holds 16 systems x 12 records
+    (t0 + 11 intervals) of 288 bytes for test/bdb/test.4.in.txt"""
+    O = oracle
+    base = tmp_path / "log"
+    run("integrate", "-I", os.path.join(GOLDEN, "bdb", "test.4.in.txt"), "integrator=hermite_adap_log",
+        "time_step_factor=170e-4", "min_time_step=0.00001", "log_interval=0.1", "destination_time=1",
+        "log_writer=binary", "log_output=%s" % base)
+    raw = open(str(base) + ".raw", "rb").read()
+    recs = O.parse_log(raw)
+    e = O.load_text(os.path.join(GOLDEN, "bdb", "test.4.in.txt"))
+    olog = O.Log(1 << 20)
+    O.integrate(e, O.params("hermite_adap", 1.0, time_step_factor=170e-4, min_time_step=1e-5),
+                O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), olog)
+    assert len(recs) == len(olog.records()) and all(r["len"] == 288 for r in recs)
+    assert (np.bincount([r["sys"] for r in recs]) == np.bincount([r["sys"] for r in olog.records()])).all()

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Kernel-level timing of any integrator/config on one GPU (not the headline bench).
+Prints one JSON line: accepted/attempted system-steps per second, kernel ms (HIP events)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import swarm_amd as S
+
+WORKLOADS = {
+    # BASELINE.json configs
+    "c2": dict(integrator="hermite", nsys=65536, nbod=3, T=2.0, cfg={"time_step": "0.0001"}),
+    "c3": dict(integrator="rkck_adaptive", nsys=65536, nbod=6, T=1.0,
+               cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27",
+                    "deactivate_on_ejection": "1", "rmax": "1000"}),
+    "c4": dict(integrator="mvs", nsys=131072, nbod=8, T=10.0, cfg={"time_step": "0.01"}),  # one 1/8 shard of 2^20
+    "c5": dict(integrator="hermite_adap_log", nsys=65536, nbod=4, T=1.0,
+               cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001", "log_interval": "0.1"}, log=400 << 20),
+    "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=1.0,
+                     cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=sorted(WORKLOADS))
+    ap.add_argument("--nsys", type=int)
+    ap.add_argument("--nbod", type=int)
+    ap.add_argument("--T", type=float)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--spread", type=float, default=0.0, help="scale systems geometrically by up to this factor")
+    a = ap.parse_args()
+    w = dict(WORKLOADS[a.workload])
+    nsys, nbod, T = a.nsys or w["nsys"], a.nbod or w["nbod"], a.T or w["T"]
+    S.capi.check(S.capi.lib.swarm_hip_init(0))
+    L = S.capi.lib
+    host0 = S.generate_ensemble(S.config({"nsys": str(nsys), "nbod": str(nbod)}))
+    if a.spread > 1:
+        s = np.geomspace(1.0 / a.spread, 1.0, nsys)[:, None, None]
+        host0.pos *= s
+        host0.vel /= np.sqrt(s)
+    cfg = dict(w["cfg"], integrator=w["integrator"])
+    res = []
+    for rep in range(a.reps):
+        host = host0.clone()
+        integ = S.Integrator.create(S.config(cfg))
+        integ.set_ensemble(host)
+        integ.set_destination_time(T)
+        if a.block:
+            integ.args.block_size = a.block
+        lm = None
+        if w.get("log"):
+            lm = S.LogManager(w["log"], "host")
+            integ.set_log_manager(lm)
+        integ.enable_step_counters()
+        integ.upload_ensemble()
+        e0 = C.c_void_p(); e1 = C.c_void_p()
+        L.swarm_hip_event_create(C.byref(e0)); L.swarm_hip_event_create(C.byref(e1))
+        L.swarm_hip_event_record(e0, None)
+        t0 = time.perf_counter()
+        attempts = integ.core_integrate()
+        L.swarm_hip_event_record(e1, None)
+        ms = C.c_float()
+        L.swarm_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+        wall = time.perf_counter() - t0
+        acc, att = integ.step_counts()
+        integ.download_ensemble()
+        res.append(dict(ms=ms.value, wall_ms=wall * 1e3, accepted=int(acc.sum()), attempted=int(att.sum()),
+                        attempts=attempts, log_bytes=len(lm.host) if lm else 0, dropped=lm.dropped if lm else 0,
+                        states={int(k): int(v) for k, v in zip(*np.unique(host.state, return_counts=True))}))
+    best = min(res, key=lambda r: r["ms"])
+    out = dict(workload=a.workload, integrator=w["integrator"], nsys=nsys, nbod=nbod, T=T, **best)
+    out["accepted_steps_per_s"] = best["accepted"] / (best["ms"] * 1e-3)
+    out["attempted_steps_per_s"] = best["attempted"] / (best["ms"] * 1e-3)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
