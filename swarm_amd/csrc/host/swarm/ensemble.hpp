@@ -126,8 +126,8 @@ public:
         return e;
     }
     bool empty() const { return !d; }
-    int nsys() const { return d->nsys; }
-    int nbod() const { return d->nbod; }
+    int nsys() const { return d ? d->nsys : 0; }
+    int nbod() const { return d ? d->nbod : 0; }
     SystemRef operator[](int i) const { return SystemRef{d.get(), i}; }
     Data &data() const { return *d; }
 

@@ -168,6 +168,7 @@ void integrator::release_device() {
 void integrator::set_ensemble(defaultEnsemble &ens) {
     _ens = ens;
     release_device();
+    if (ens.empty()) return; // an unset ensemble (swarm.cpp:219-220 sets the real one next)
     _dens.nsys = ens.nsys();
     _dens.nbod = ens.nbod();
     _dens.nbattr = ensemble::NUM_BODY_ATTRIBUTES;
