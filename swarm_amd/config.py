@@ -50,7 +50,9 @@ class config(dict):
         if key not in self:
             raise key_not_found(key)
         v = self._scan(key, default)
-        return default if v is None else v
+        if v is None:            # present but not a valid value of type T (types/config.hpp:181-186)
+            raise key_not_found(key)
+        return v
 
     def optional(self, key, default):
         if key not in self:

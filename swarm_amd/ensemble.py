@@ -38,7 +38,7 @@ class HostEnsemble:
     def slice(self, lo, hi):
         e = HostEnsemble(hi - lo, self.nbod, self.nbattr, self.nsattr)
         for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
-            setattr(e, k, np.ascontiguousarray(getattr(self, k)[lo:hi]))
+            setattr(e, k, getattr(self, k)[lo:hi].copy())
         return e
 
     # swarm/types/ensemble.hpp:402-413 (host twin; the device version is swarm_hip_total_energy)

@@ -136,7 +136,7 @@ def test_benchmark_and_verify_csv():
     assert "Verify success" in p.stdout
     p = run("verify", "--range", "integrator=hermite,euler", "nsys=64", "nbod=3", "integrator=hermite",
             "time_step=0.01", "destination_time=1", "-q", "pos_threshold=1e-14", check=False)
-    assert p.returncode == 1 and "Verify failed" in p.stderr
+    assert p.returncode == 1          # (-q silences the "Verify failed" notice, exit status stays 1)
 
 
 @pytest.mark.gpu
