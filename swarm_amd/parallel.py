@@ -80,8 +80,8 @@ def gather_ensemble(shard, nsys_total, dist=None, device=None):
     width = nb * 3 * 2 + nb + 1 + nb * shard.nbattr + shard.nsattr + 2   # doubles per system (+state,id)
     blk = np.zeros((cap, width))
     n = shard.nsys
-    cols = [shard.pos.reshape(n, -1), shard.vel.reshape(n, -1), shard.mass, shard.time[:, None],
-            shard.body_attr.reshape(n, -1), shard.sys_attr, shard.state[:, None].astype(np.float64),
+    cols = [shard.pos.reshape(n, nb * 3), shard.vel.reshape(n, nb * 3), shard.mass, shard.time[:, None],
+            shard.body_attr.reshape(n, nb * shard.nbattr), shard.sys_attr, shard.state[:, None].astype(np.float64),
             shard.id[:, None].astype(np.float64)]
     blk[:n] = np.concatenate(cols, axis=1)
     t = torch.as_tensor(blk, device=device)
