@@ -74,5 +74,5 @@ def test_shard_bounds_properties():
             b = P.shard_bounds(nsys, world)
             assert b[0][0] == 0 and b[-1][1] == nsys
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
-            assert all(lo % 64 == 0 for lo, hi in b)
+            assert all(lo % 64 == 0 or lo == hi == nsys for lo, hi in b)
     assert P.shard_bounds(1 << 20, 8) == [(r * 131072, (r + 1) * 131072) for r in range(8)]
