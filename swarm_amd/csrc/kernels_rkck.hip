@@ -5,7 +5,8 @@
 // retires on its own; the wavefront runs until its last system is done or the iteration budget
 // (destination_time / max_time_step attempts, rkck_integrator.hpp:75,143) is used up.
 //
-// Deviation from the reference, on purpose: after a REJECTED attempt the reference leaves
+// Deviations from the reference, on purpose: (1) stage velocities are not stored, see the comment
+// above rkck_kernel; (2) after a REJECTED attempt the reference leaves
 // p6^2, v6^2 in the global ensemble (L221) until the next force evaluation overwrites them, so a
 // launch whose budget ends on a reject hands back squares.  Here state is only written from the
 // last ACCEPTED step.
@@ -13,20 +14,42 @@
 
 namespace swh {
 
+// Cash-Karp tableau, rkck_integrator.hpp:96-108 (row k = coefficients of stage k+1)
+struct CK {
+    static constexpr double b[6][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {1.0 / 5.0, 0, 0, 0, 0, 0},
+        {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0},
+        {0.3, -0.9, 1.2, 0, 0, 0},
+        {-11.0 / 54.0, 2.5, -70.0 / 27.0, 35.0 / 27.0, 0, 0},
+        {1631.0 / 55296.0, 175.0 / 512.0, 575.0 / 13824.0, 44275.0 / 110592.0, 253.0 / 4096.0, 0}};
+    static constexpr double b6[6] = {37.0 / 378.0, 0, 250.0 / 621.0, 125.0 / 594.0, 0, 512.0 / 1771.0};
+    static constexpr double ecc[6] = {37.0 / 378.0 - 2825.0 / 27648.0, 0.0, 250.0 / 621.0 - 18575.0 / 48384.0,
+                                      125.0 / 594.0 - 13525.0 / 55296.0, -277.00 / 14336.0, 512.0 / 1771.0 - 0.25};
+    // weights w (length 6) over stage velocities k_vel[i] = vel + h * sum_j b[i][j] k_acc[j]:
+    //   sum_i w[i] k_vel[i] = rowsum(w) * vel + h * sum_j second(w, j) * k_acc[j]
+    static constexpr double rowsum(const double (&w)[6], int n) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += w[i];
+        return s;
+    }
+    static constexpr double second(const double (&w)[6], int n, int j) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += w[i] * b[i][j];
+        return s;
+    }
+};
+
+// The reference keeps k_vel[1..6] and k_acc[1..6] per (body,component) in registers of 3*nbod
+// threads.  With one lane per system that is 12 * 3 * nbod doubles per lane (nbod=6: 432 VGPRs)
+// before any temporaries.  The stage velocities are linear in vel and k_acc, so only k_acc is
+// kept and every stage position is formed as
+//     p_k = pos + h * (c_k * vel + h * sum_j B2[k][j] * k_acc[j]),  B2 = b * b, c_k = rowsum(b[k])
+// which is the same polynomial as the reference's `pos + h*(b[k][0]*k1_vel + ...)` (L158-194)
+// with the products of tableau constants folded at compile time.
 template <int N, bool ADAPTIVE, bool MON>
 __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                    Counters cnt) {
-    // Cash-Karp constants, rkck_integrator.hpp:96-108
-    const double b1 = 1.0 / 5.0;
-    const double b2[] = {3.0 / 40.0, 9.0 / 40.0};
-    const double b3[] = {0.3, -0.9, 1.2};
-    const double b4[] = {-11.0 / 54.0, 2.5, -70.0 / 27.0, 35.0 / 27.0};
-    const double b5[] = {1631.0 / 55296.0, 175.0 / 512.0, 575.0 / 13824.0, 44275.0 / 110592.0,
-                         253.0 / 4096.0};
-    const double b6[] = {37.0 / 378.0, 0, 250.0 / 621.0, 125.0 / 594.0, 0, 512.0 / 1771.0};
-    const double ecc[] = {37.0 / 378.0 - 2825.0 / 27648.0, 0.0, 250.0 / 621.0 - 18575.0 / 48384.0,
-                          125.0 / 594.0 - 13525.0 / 55296.0, -277.00 / 14336.0, 512.0 / 1771.0 - 0.25};
-
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= e.nsys) return;
     State<N> s;
@@ -47,78 +70,76 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 #pragma clang fp contract(off)
             if (s.t + h > dest) h = dest - s.t;
         }
-        double kv[6][N][3], ka[6][N][3];
-        double sp[N][3], sv[N][3];
+        double ka[6][N][3];
+        double sp[N][3];
 #pragma unroll
         for (int b = 0; b < N; b++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) sp[b][c] = s.p[b][c], sv[b][c] = s.v[b][c];
+            for (int c = 0; c < 3; c++) sp[b][c] = s.p[b][c];
 
+        // stages 1..6: ka[k] = acc(p_k); p_{k+1} from (pos, vel, ka[0..k])
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             acc_only<N, false>(sp, s.m, ka[k]);
+            if (k < 5) {
+                const double ck = CK::rowsum(CK::b[k + 1], 6);
 #pragma unroll
-            for (int b = 0; b < N; b++)
+                for (int b = 0; b < N; b++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    kv[k][b][c] = sv[b][c];
-                    double sumv, suma;
-#define KV(i) kv[i][b][c]
-#define KA(i) ka[i][b][c]
-                    if (k == 0) {
-                        sp[b][c] = s.p[b][c] + h * b1 * KV(0);
-                        sv[b][c] = s.v[b][c] + h * b1 * KA(0);
-                        continue;
-                    } else if (k == 1) {
-                        sumv = b2[0] * KV(0) + b2[1] * KV(1);
-                        suma = b2[0] * KA(0) + b2[1] * KA(1);
-                    } else if (k == 2) {
-                        sumv = b3[0] * KV(0) + b3[1] * KV(1) + b3[2] * KV(2);
-                        suma = b3[0] * KA(0) + b3[1] * KA(1) + b3[2] * KA(2);
-                    } else if (k == 3) {
-                        sumv = b4[0] * KV(0) + b4[1] * KV(1) + b4[2] * KV(2) + b4[3] * KV(3);
-                        suma = b4[0] * KA(0) + b4[1] * KA(1) + b4[2] * KA(2) + b4[3] * KA(3);
-                    } else if (k == 4) {
-                        sumv = b5[0] * KV(0) + b5[1] * KV(1) + b5[2] * KV(2) + b5[3] * KV(3) + b5[4] * KV(4);
-                        suma = b5[0] * KA(0) + b5[1] * KA(1) + b5[2] * KA(2) + b5[3] * KA(3) + b5[4] * KA(4);
-                    } else {
-                        sumv = b6[0] * KV(0) + b6[1] * KV(1) + b6[2] * KV(2) + b6[3] * KV(3) +
-                               b6[4] * KV(4) + b6[5] * KV(5);
-                        suma = b6[0] * KA(0) + b6[1] * KA(1) + b6[2] * KA(2) + b6[3] * KA(3) +
-                               b6[4] * KA(4) + b6[5] * KA(5);
+                    for (int c = 0; c < 3; c++) {
+                        double acc2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < k; j++) { // second(b[k+1], j) is zero for j >= k
+                            const double w = CK::second(CK::b[k + 1], 6, j);
+                            acc2 = (j == 0) ? w * ka[j][b][c] : __builtin_fma(w, ka[j][b][c], acc2);
+                        }
+                        const double inner = (k == 0) ? ck * s.v[b][c] : __builtin_fma(h, acc2, ck * s.v[b][c]);
+                        sp[b][c] = __builtin_fma(h, inner, s.p[b][c]);
                     }
-                    sp[b][c] = s.p[b][c] + h * sumv;
-                    sv[b][c] = s.v[b][c] + h * suma;
-                }
+            }
         }
-        // sp, sv now hold p6, v6
+        // 5th-order solution (p6, v6) and the embedded error estimate (L193-199)
+        double p6[N][3], v6[N][3];
+        double max_error = 0;
+#pragma unroll
+        for (int b = 0; b < N; b++) {
+            double pem = 0, vem = 0, pm = 0, vm = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double sa = 0, sa2 = 0, ea = 0, ea2 = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double kj = ka[j][b][c];
+                    sa = (j == 0) ? CK::b6[0] * kj : __builtin_fma(CK::b6[j], kj, sa);
+                    sa2 = (j == 0) ? CK::second(CK::b6, 6, 0) * kj : __builtin_fma(CK::second(CK::b6, 6, j), kj, sa2);
+                    if (ADAPTIVE) {
+                        ea = (j == 0) ? CK::ecc[0] * kj : __builtin_fma(CK::ecc[j], kj, ea);
+                        ea2 = (j == 0) ? CK::second(CK::ecc, 6, 0) * kj : __builtin_fma(CK::second(CK::ecc, 6, j), kj, ea2);
+                    }
+                }
+                v6[b][c] = __builtin_fma(h, sa, s.v[b][c]);
+                p6[b][c] = __builtin_fma(h, __builtin_fma(h, sa2, CK::rowsum(CK::b6, 6) * s.v[b][c]), s.p[b][c]);
+                if (ADAPTIVE) {
+                    const double ve = h * ea;
+                    const double pe = h * __builtin_fma(h, ea2, CK::rowsum(CK::ecc, 6) * s.v[b][c]);
+                    pem = (c == 0) ? pe * pe : pem + pe * pe;
+                    vem = (c == 0) ? ve * ve : vem + ve * ve;
+                    pm = (c == 0) ? p6[b][c] * p6[b][c] : pm + p6[b][c] * p6[b][c];
+                    vm = (c == 0) ? v6[b][c] * v6[b][c] : vm + v6[b][c] * v6[b][c];
+                }
+            }
+            if (ADAPTIVE) {
+                const double pen = pem / pm, ven = vem / vm; // L232-238
+                max_error = fmax(fmax(pen, ven), max_error);
+            }
+        }
         bool accept_step = true;
-        if (ADAPTIVE) { // L204-269
+        if (ADAPTIVE) { // L204-269: float constants, pow() on the normalised error
             const float step_grow_power = -1. / (5 + 1.);
             const float step_shrink_power = -1. / 5;
             const float step_guess_safety_factor = 0.9;
             const float step_grow_max_factor = 5.0;
             const float step_shrink_min_factor = 0.2;
-            double max_error = 0;
-#pragma unroll
-            for (int b = 0; b < N; b++) {
-                double pem = 0, vem = 0, pm = 0, vm = 0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const double pe = h * (ecc[0] * KV(0) + ecc[1] * KV(1) + ecc[2] * KV(2) + ecc[3] * KV(3) +
-                                           ecc[4] * KV(4) + ecc[5] * KV(5));
-                    const double ve = h * (ecc[0] * KA(0) + ecc[1] * KA(1) + ecc[2] * KA(2) + ecc[3] * KA(3) +
-                                           ecc[4] * KA(4) + ecc[5] * KA(5));
-                    pem = (c == 0) ? pe * pe : pem + pe * pe;
-                    vem = (c == 0) ? ve * ve : vem + ve * ve;
-                    pm = (c == 0) ? sp[b][c] * sp[b][c] : pm + sp[b][c] * sp[b][c];
-                    vm = (c == 0) ? sv[b][c] * sv[b][c] : vm + sv[b][c] * sv[b][c];
-                }
-                const double pen = pem / pm, ven = vem / vm;
-                max_error = fmax(fmax(pen, ven), max_error);
-            }
-#undef KV
-#undef KA
             const double normalized_error = max_error / ip.error_tolerance;
             const double step_guess_power = (normalized_error < 1.) ? step_grow_power : step_shrink_power;
             const double step_change_factor =
@@ -139,7 +160,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 #pragma unroll
             for (int b = 0; b < N; b++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) s.p[b][c] = sp[b][c], s.v[b][c] = sv[b][c];
+                for (int c = 0; c < 3; c++) s.p[b][c] = p6[b][c], s.v[b][c] = v6[b][c];
             s.t += h;
             accepted++;
         }
