@@ -130,21 +130,23 @@ def main():
     kernel_ms_avg = sum(kernel_ms) / max(len(kernel_ms), 1)
 
     # ---- post-run checks and the multi-GPU exchange (outside the timed region) ----
+    from swarm_amd import parallel as P
     e1 = dens.total_energy()
     derr = np.abs((e1 - e0) / e0)
     final = dens.download()
     expect_t = (args.warmup + args.steps) * args.span
     assert np.allclose(final.time, expect_t, rtol=1e-9), (final.time[:3], expect_t)
-    stats = torch.tensor([derr.sum(), float((final.state == -1).sum()), float(nsys)], dtype=torch.float64, device=dev)
-    mx = torch.tensor([derr.max()], dtype=torch.float64, device=dev)
+    # energy / ejection statistics: one small all-reduce (sum, max, min) over RCCL
+    stats = P.allreduce_stats(*P.local_stats(derr, final.state, steps_accepted=nsys * steps_per_pass * args.steps),
+                              dist=dist, device=dev)
     gather_ms = None
     if dist is not None:
-        dist.all_reduce(stats)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        shards = [torch.empty_like(tb) for _ in range(world)]
+        # final ensemble gather: the device shards are contiguous byte ranges, one all_gather each
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.all_gather(shards, tb)  # final ensemble gather over RCCL/xGMI
+        for t in (tb, td, ti):
+            shards = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(shards, t)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -182,8 +184,8 @@ def main():
                      "flop_per_system_step": flops,
                      "note": "bound is the FP64 vector ALU (not HBM, not MFMA): state is register-resident for "
                              "all %d steps of a launch; HBM bytes per launch are negligible" % steps_per_pass},
-        "energy": {"max_rel_err": float(mx.item()), "mean_rel_err": float(stats[0].item() / stats[2].item()),
-                   "n_disabled": int(stats[1].item())},
+        "energy": {"max_rel_err": stats["max_abs_dE_over_E"], "mean_rel_err": stats["mean_abs_dE_over_E"],
+                   "n_disabled": int(stats["n_disabled"]), "n_systems": int(stats["nsys"])},
     }
     if gather_ms is not None:
         out["gather_ms"] = gather_ms

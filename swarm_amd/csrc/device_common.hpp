@@ -107,6 +107,19 @@ __device__ __forceinline__ double rsqrt_full(double x) {
     return __builtin_fma(y * e, q, y);          // y*(1 + e/2 + 3/8 e^2)
 }
 
+// 1/x and a/b, sqrt(x) to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64, 2^-24) and one
+// third-order Newton step.  Measured on MI355X (profiles/r1/fp64_valu_ubench.txt): the IEEE
+// divide costs ~60 and the IEEE sqrt ~85 cycles per wave-instruction; these cost ~35 / ~45.
+// Used where the reference's CUDA code has plain `/` and sqrt() in the MVS Kepler solver.
+__device__ __forceinline__ double rcp_full(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    double t = __builtin_fma(e, e, e); // e + e^2
+    return __builtin_fma(r, t, r);
+}
+__device__ __forceinline__ double fdiv(double a, double b) { return a * rcp_full(b); }
+__device__ __forceinline__ double fsqrt(double x) { return x > 0.0 ? x * rsqrt_full(x) : (x == 0.0 ? 0.0 : __builtin_nan("")); }
+
 // Pairwise acceleration + jerk, all bodies of one system in registers.
 // Arithmetic follows hermite_cpu::calcForces (integrators/hermite_cpu.hpp:82-110): pairs i<j in
 // lexicographic order, one accumulator per body, scalar = r^-3 * m_other; with

@@ -40,8 +40,8 @@ __device__ __forceinline__ double solvex(double r0dotv0, double alpha, double sq
     const double N_LAG = 5.0;
     const double smu = sqrtM1;
     const double foo = 1.0 - r0 * alpha;
-    const double sig0 = r0dotv0 / smu;
-    double x = sqrtM1 * sqrtM1 * dt * dt / r0;
+    const double sig0 = fdiv(r0dotv0, smu);
+    double x = fdiv(sqrtM1 * sqrtM1 * dt * dt, r0);
     double u = 1.0;
     for (int i = 0; (i < 7) && !((i > 2) && (x + u == x)); i++) {
         const double x2 = x * x, x3 = x2 * x, alx2 = alpha * x2;
@@ -51,10 +51,10 @@ __device__ __forceinline__ double solvex(double r0dotv0, double alpha, double sq
         const double dF = sig0 * x * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
         const double ddF = sig0 * (1.0 - alx2 * Cp) + foo * x * (1.0 - alx2 * Sp);
         double z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
-        z = sqrt(z);
+        z = fsqrt(z);
         double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
         if (denom == 0.0) denom = 1e-8;
-        u = N_LAG * F / denom;
+        u = fdiv(N_LAG * F, denom);
         x -= u;
     }
     return x;
@@ -64,28 +64,28 @@ __device__ __forceinline__ double solvex(double r0dotv0, double alpha, double sq
 __device__ __forceinline__ void drift_kepler(double (&p)[3], double (&v)[3], const double sqrtGM,
                                              const double deltaTime) {
     const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
-    const double r0 = sqrt(x_old * x_old + y_old * y_old + z_old * z_old);
+    const double r0 = fsqrt(x_old * x_old + y_old * y_old + z_old * z_old);
     const double v2 = (vx_old * vx_old + vy_old * vy_old + vz_old * vz_old);
     const double r0dotv0 = (x_old * vx_old + y_old * vy_old + z_old * vz_old);
     const double GM = sqrtGM * sqrtGM;
-    const double alpha = (2.0 / r0 - v2 / GM);
+    const double alpha = (fdiv(2.0, r0) - fdiv(v2, GM));
     const double x_p = solvex(r0dotv0, alpha, sqrtGM, r0, deltaTime);
     const double smu = sqrtGM;
     const double foo = 1.0 - r0 * alpha;
-    const double sig0 = r0dotv0 / smu;
+    const double sig0 = fdiv(r0dotv0, smu);
     const double x2 = x_p * x_p, x3 = x2 * x_p, alx2 = alpha * x2;
     double Cp, Sp;
     SC_prussing(alx2, Sp, Cp);
     double r = sig0 * x_p * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
     if (r < 0.) r = 0.;
-    const double f_p = 1.0 - (x2 / r0) * Cp;
-    const double g_p = deltaTime - (x3 / smu) * Sp;
+    const double f_p = 1.0 - fdiv(x2, r0) * Cp;
+    const double g_p = deltaTime - fdiv(x3, smu) * Sp;
     double dfdt;
-    const double dgdt = 1.0 - (x2 / r) * Cp;
+    const double dgdt = 1.0 - fdiv(x2, r) * Cp;
     if (fabs(g_p) > 1e-8)
-        dfdt = (f_p * dgdt - 1.0) / g_p;
+        dfdt = fdiv(f_p * dgdt - 1.0, g_p);
     else
-        dfdt = x_p * smu / (r * r0) * (alx2 * Sp - 1.0);
+        dfdt = fdiv(x_p * smu, r * r0) * (alx2 * Sp - 1.0);
     p[0] = f_p * x_old + g_p * vx_old;
     p[1] = f_p * y_old + g_p * vy_old;
     p[2] = f_p * z_old + g_p * vz_old;
