@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--span", type=float, default=2.0, help="destination_time advance per bench step")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=18.0)
     args = ap.parse_args()
 
     import numpy as np
