@@ -37,10 +37,12 @@ public:
     virtual void process(const char *p, size_t n) { bytes.insert(bytes.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
 };
 
-// appends the raw gpulog record stream to <log_output>.raw (the reference's binary_writer also
-// prepends a swarm_header and sorts on close, log/binary_writer.cpp:39-91 -- "next" row N2)
+// log/binary_writer.cpp:39-91: swarm_header("unsorted_output") + the raw gpulog record stream go
+// to <log_output>.raw; on close the file is sorted by (time, system) into <log_output> and the
+// .raw file is removed.  (The reference also pre-builds .time.idx/.sys.idx index files.)
 class binary_writer : public writer {
     FILE *f;
+    std::string rawfn, binfn;
 public:
     binary_writer(const config &cfg);
     virtual ~binary_writer();

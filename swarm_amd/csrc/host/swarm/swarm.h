@@ -6,6 +6,7 @@
 #include "integrator.hpp"
 #include "log.hpp"
 #include "plugin.hpp"
+#include "query.hpp"
 #include "snapshot.hpp"
 #include "utils.hpp"
 

@@ -1,7 +1,7 @@
 // swarm_cli.cpp -- the `swarm` command line tool over the MI355X kernels: integrate, test,
 // benchmark, verify, generate, convert.  Mirrors swarm/swarm.cpp of the reference (same options,
 // same key=value positional pairs, same CSV and messages); boost::program_options is replaced by
-// a small hand-written parser.  `query` needs the log file readers and is absent.
+// a small hand-written parser.  `query` reads binary log files (no Berkeley DB, no -k output).
 #include <sys/time.h>
 
 #include <cmath>
@@ -263,6 +263,7 @@ static const char *USAGE =
     "\tintegrate :  Integrate a [loaded|generated] ensemble\n"
     "\tbenchmark :  Compare outputs for different methods of integrations\n"
     "\tverify    :  Verify an integrator against a reference integrator\n"
+    "\tquery     :  Query data from a log file\n"
     "\ttest      :  Test a configuration against input/output files\n"
     "\tgenerate  :  Generate a new ensemble and save it to output file\n"
     "\tconvert   :  Read input file and write it to output file (converts to/from text)\n"
@@ -284,7 +285,16 @@ static const char *USAGE =
     "  -I [ --text_input ] arg       Text Input file\n"
     "  -O [ --text_output ] arg      Text Output file\n"
     "Benchmark Options:\n"
-    "  --range arg                   Parameter value range param=v1,v2,v3\n";
+    "  --range arg                   Parameter value range param=v1,v2,v3\n"
+    "Query Options:\n"
+    "  -t [ --time ] arg             range of times to query\n"
+    "  -s [ --system ] arg           range of systems to query\n"
+    "  -b [ --body ] arg             range of bodies to query\n"
+    "  --astrocentric                output coordinates in astrocentric frame\n"
+    "  --barycentric                 output coordinates in barycentric frame\n"
+    "  --origin                      output coordinates in origin frame\n"
+    "  --jacobi                      output coordinates in Jacobi frame [default]\n"
+    "  -f [ --logfile ] arg          the log file to query\n";
 
 static void parse_commandline_and_config(int argc, char *argv[]) { // swarm.cpp:435-559
     struct opt { const char *lng; char sht; bool arg; };
@@ -292,7 +302,10 @@ static void parse_commandline_and_config(int argc, char *argv[]) { // swarm.cpp:
                                {"input", 'i', true}, {"output", 'o', true}, {"text_input", 'I', true},
                                {"text_output", 'O', true}, {"range", 0, true}, {"cfg", 'c', true}, {"nogpu", 'g', false},
                                {"defaults", 0, false}, {"help", 'h', false}, {"plugins", 'p', false},
-                               {"verbose", 'v', true}, {"quiet", 'q', false}, {"version", 'V', false}};
+                               {"verbose", 'v', true}, {"quiet", 'q', false}, {"version", 'V', false},
+                               {"time", 't', true}, {"system", 's', true}, {"body", 'b', true}, {"logfile", 'f', true},
+                               {"astrocentric", 0, false}, {"barycentric", 0, false}, {"origin", 0, false},
+                               {"jacobi", 0, false}, {"keplerian", 'k', false}};
     vector<string> positional;
     for (int i = 1; i < argc; i++) {
         string a = argv[i];
@@ -370,6 +383,22 @@ static int real_main(int argc, char *argv[]) {
             cout << (verification_results ? "Verify success" : "Verify failed") << endl;
             return verification_results ? 0 : 1;
         }
+    } else if (command == "query") { // swarm.cpp:602-646
+        using namespace query;
+        if (!argvars.count("logfile")) { cerr << "Name of input log file is missing \n"; return 1; }
+        if (argvars.count("keplerian")) ERROR("Keplerian output is not supported by this build");
+        time_range_t T;
+        sys_range_t sys, body_range;
+        if (argvars.count("time")) T = time_range_t::parse(argvars["time"]);
+        if (argvars.count("system")) sys = sys_range_t::parse(argvars["system"]);
+        if (argvars.count("body")) body_range = body_range_t::parse(argvars["body"]);
+        if (argvars.count("origin")) query::set_coordinate_system(query::origin);
+        if (argvars.count("astrocentric")) query::set_coordinate_system(query::astrocentric);
+        if (argvars.count("barycentric")) query::set_coordinate_system(query::barycentric);
+        if (argvars.count("jacobi")) query::set_coordinate_system(query::jacobi);
+        std::cout.flush();
+        std::cerr << "# Output in Cartesian coordinates  \n";
+        query::execute(argvars["logfile"], T, sys, body_range);
     } else if (command == "generate") {
         INFO_OUTPUT(1, "Generating new ensemble:  " << cfg["nsys"] << ", " << cfg["nbod"] << endl);
         current_ens = generate_ensemble(cfg);
@@ -382,7 +411,7 @@ static int real_main(int argc, char *argv[]) {
             exit(1);
         }
     } else
-        std::cerr << "Valid commands are: integrate, benchmark, verify, test, generate, convert " << std::endl;
+        std::cerr << "Valid commands are: integrate, benchmark, verify, test, query, generate " << std::endl;
     return 0;
 }
 

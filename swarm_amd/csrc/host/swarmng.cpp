@@ -4,6 +4,11 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <unistd.h>
+
+#include <algorithm>
+#include <fstream>
+#include <regex>
 
 #include "swarm/swarm.h"
 
@@ -55,16 +60,27 @@ writer *writer::create(const config &cfg) {
 }
 
 binary_writer::binary_writer(const config &cfg) {
-    std::string fn = cfg.require("log_output", std::string()) + ".raw";
-    f = fopen(fn.c_str(), "wb");
-    if (!f) ERROR("Could not open '" + fn + "' for writing");
+    binfn = cfg.optional("log_output", std::string());
+    if (binfn == "") ERROR("Expected filename for writer.");
+    rawfn = binfn + ".raw";
+    f = fopen(rawfn.c_str(), "wb");
+    if (!f) ERROR("Could not open '" + rawfn + "' for writing");
+    swarm_header fh(query::UNSORTED_HEADER_FULL);
+    fwrite(&fh, 1, sizeof(fh), f);
 }
-binary_writer::~binary_writer() { if (f) fclose(f); }
+binary_writer::~binary_writer() {
+    if (f) fclose(f);
+    f = 0;
+    try {
+        if (query::sort_binary_log_file(binfn, rawfn)) unlink(rawfn.c_str());
+    } catch (...) {
+    }
+}
 void binary_writer::process(const char *p, size_t n) { if (n) fwrite(p, 1, n, f); }
 
 static writer_plugin_initializer<null_writer> null_writer_plugin("null", "This is the dummy writer");
 static writer_plugin_initializer<host_array_writer> host_array_writer_plugin("host_array", "Keeps the log in host memory");
-static writer_plugin_initializer<binary_writer> binary_writer_plugin("binary", "Raw gpulog record stream to <log_output>.raw");
+static writer_plugin_initializer<binary_writer> binary_writer_plugin("binary", "This is the binary writer");
 
 manager::~manager() {
     if (d_buf) swarm_hip_free(d_buf);
@@ -409,6 +425,166 @@ void save_text(defaultEnsemble &ens, const std::string &filename) {
 }
 
 } // namespace snapshot
+
+// ---- binary log files and query: swarm/log/io.cpp, swarm/query.cpp ------------------------------
+std::string swarm_header::type() const {
+    const char *c = strstr(m_type, "//");
+    if (!c) return trim(m_type);
+    return trim(std::string(m_type, c - m_type));
+}
+
+namespace query {
+
+const char *UNSORTED_HEADER_FULL = "unsorted_output // Unsorted output file";
+const char *UNSORTED_HEADER_CHECK = "unsorted_output";
+const char *SORTED_HEADER_FULL = "T_sorted_output // Output file sorted by time";
+const char *SORTED_HEADER_CHECK = "T_sorted_output";
+
+static planets_coordinate_system_t planets_coordinate_system = jacobi; // query.cpp:65
+void set_coordinate_system(const planets_coordinate_system_t &c) { planets_coordinate_system = c; }
+
+template <typename T> static T arg_parse(const std::string &s) {
+    if (s == "MIN") return range<T>().first;
+    if (s == "MAX") return range<T>().last;
+    return (T)atof(s.c_str());
+}
+template <typename T> range<T> range<T>::parse(const std::string &s) {
+    if (s == "ALL") return range<T>();
+    static std::regex r("(.+?)(?:\\.\\.(.+))?");
+    std::smatch match;
+    if (!std::regex_match(s, match, r)) ERROR("invalid value '" + s + "' for a range");
+    if (match[2] == "") return range<T>(arg_parse<T>(match[1]));
+    return range<T>(arg_parse<T>(match[1]), arg_parse<T>(match[2]));
+}
+template struct range<int>;
+template struct range<double>;
+
+// one record of the gpulog stream: header {int msgid; int len}, then (double T, int sys, ...)
+struct rec_t {
+    const char *ptr;
+    int len;
+    int msgid() const { int v; memcpy(&v, ptr, 4); return v; }
+    double T() const { double v; memcpy(&v, ptr + 8, 8); return v; }
+    int sys() const { int v; memcpy(&v, ptr + 16, 4); return v; }
+    bool operator<(const rec_t &a) const { // idx_t::operator<, io.cpp:72-84
+        double Tt = T(), Ta = a.T();
+        int syst = sys(), sysa = a.sys();
+        return Tt < Ta || (Tt == Ta && (syst < sysa || (syst == sysa && ptr < a.ptr)));
+    }
+};
+
+static std::vector<char> read_log_file(const std::string &fn, std::string &type) {
+    std::ifstream in(fn.c_str(), std::ios::binary);
+    if (!in) ERROR("Could not open '" + fn + "' for reading");
+    std::vector<char> all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if (all.size() < sizeof(swarm_header) || memcmp(all.data(), "SWARM\0" "0\0", 8) != 0)
+        ERROR("'" + fn + "' is not a swarm log file");
+    swarm_header fh("");
+    memcpy((void *)&fh, all.data(), sizeof(fh));
+    type = fh.type();
+    return std::vector<char>(all.begin() + sizeof(swarm_header), all.end());
+}
+
+static std::vector<rec_t> index_records(const std::vector<char> &data) {
+    std::vector<rec_t> idx;
+    size_t off = 0;
+    while (off + 8 <= data.size()) {
+        rec_t r;
+        r.ptr = data.data() + off;
+        memcpy(&r.len, r.ptr + 4, 4);
+        if (r.len <= 0 || off + (size_t)r.len > data.size()) ERROR("corrupt log record");
+        idx.push_back(r);
+        off += (size_t)r.len;
+    }
+    return idx;
+}
+
+bool sort_binary_log_file(const std::string &outfn, const std::string &infn) {
+    std::string type;
+    std::vector<char> data = read_log_file(infn, type);
+    if (type != UNSORTED_HEADER_CHECK) ERROR("'" + infn + "' is not an unsorted log file");
+    std::vector<rec_t> idx = index_records(data);
+    std::sort(idx.begin(), idx.end());
+    std::ofstream out(outfn.c_str(), std::ios::binary);
+    if (!out) ERROR("Could not open '" + outfn + "' for writing");
+    swarm_header fh(SORTED_HEADER_FULL, 0, data.size());
+    out.write((const char *)&fh, sizeof(fh));
+    for (size_t i = 0; i != idx.size(); i++) out.write(idx[i].ptr, idx[i].len);
+    return true;
+}
+
+// log::body, log/types.hpp:37-56 (64 bytes)
+struct lbody { double x, y, z, vx, vy, vz, mass; int body_id; int pad; };
+
+static lbody center_of_mass(const lbody *bodies, const int nbod) { // query.cpp:95-119
+    lbody c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < nbod; i++) {
+        c.x += bodies[i].x * bodies[i].mass, c.y += bodies[i].y * bodies[i].mass, c.z += bodies[i].z * bodies[i].mass;
+        c.vx += bodies[i].vx * bodies[i].mass, c.vy += bodies[i].vy * bodies[i].mass, c.vz += bodies[i].vz * bodies[i].mass;
+        c.mass += bodies[i].mass;
+    }
+    c.x /= c.mass, c.y /= c.mass, c.z /= c.mass, c.vx /= c.mass, c.vy /= c.mass, c.vz /= c.mass;
+    return c;
+}
+
+// record_output_1 (EVT_SNAPSHOT), query.cpp:122-205, Cartesian branch
+static void record_output_1(std::ostream &out, const rec_t &r, const body_range_t &body_range) {
+    double time = r.T();
+    int sys = r.sys(), flags, nbod;
+    memcpy(&flags, r.ptr + 20, 4);
+    memcpy(&nbod, r.ptr + 24, 4);
+    std::vector<lbody> bodies(nbod);
+    memcpy((void *)bodies.data(), r.ptr + 32, sizeof(lbody) * nbod);
+    lbody center;
+    const lbody &star = bodies[0];
+    switch (planets_coordinate_system) {
+    case astrocentric: center = star; break;
+    case barycentric: center = center_of_mass(bodies.data(), nbod); break;
+    case jacobi: center = star; break;
+    case origin:
+        memset(&center, 0, sizeof(center));
+        center.mass = star.mass;
+        break;
+    }
+    char buf[1000];
+    for (int bod = 0; bod < nbod; bod++) {
+        if (!body_range.in(bod)) continue;
+        const lbody &b = bodies[bod];
+        if ((planets_coordinate_system == jacobi) && (bod == 0)) continue;
+        if (((planets_coordinate_system != jacobi) && (bod > 0)) || ((planets_coordinate_system == jacobi) && (bod > 1)))
+            out << "\n";
+        if (planets_coordinate_system == jacobi) center = center_of_mass(bodies.data(), bod);
+        double x = b.x - center.x, y = b.y - center.y, z = b.z - center.z;
+        double vx = b.vx - center.vx, vy = b.vy - center.vy, vz = b.vz - center.vz;
+        snprintf(buf, sizeof(buf), "%10d %lg  %6d %6d  %lg  %9.5lg %9.5lg %9.5lg  %9.5lg %9.5lg %9.5lg  %d", r.msgid(), time,
+                 sys, bod, b.mass, x, y, z, vx, vy, vz, flags);
+        out << buf;
+    }
+}
+
+void execute(const std::string &datafile, time_range_t T, sys_range_t sys, body_range_t bod, std::ostream &out) {
+    if (datafile.size() >= 3 && datafile.substr(datafile.size() - 3) == ".db")
+        ERROR("Berkeley DB log files are not supported by this build");
+    std::string type;
+    std::vector<char> data = read_log_file(datafile, type);
+    std::vector<rec_t> idx = index_records(data);
+    if (type != SORTED_HEADER_CHECK) std::sort(idx.begin(), idx.end()); // a raw file: order it first
+    for (size_t i = 0; i != idx.size(); i++) {
+        const rec_t &r = idx[i];
+        if (!T.in(r.T()) || !sys.in(r.sys())) continue;
+        if (r.msgid() == 1)
+            record_output_1(out, r, bod);
+        else { // record_output_default
+            char buf[200];
+            snprintf(buf, sizeof(buf), "%10d %lg  %6d", r.msgid(), r.T(), r.sys());
+            out << buf;
+        }
+        out << "\n";
+    }
+}
+
+} // namespace query
 
 // ---- utils: swarm/utils.cpp ------------------------------------------------------------------
 hostEnsemble generate_ensemble(config &cfg) { // utils.cpp:63-103

@@ -63,6 +63,42 @@ def test_cli_errors_and_plugin_list():
     assert p.returncode == 1 and "Possible commands are" in p.stdout
 
 
+def swarm_header(kind, datalen=0xFFFFFFFFFFFFFFFF):
+    """log/fileformat.hpp:28-68 in python: 96 bytes"""
+    import struct
+    m = {"unsorted": b"unsorted_output // Unsorted output file", "sorted": b"T_sorted_output // Output file sorted by time"}[kind]
+    return b"SWARM\0" + b"0\0" + m.ljust(76, b"\0") + struct.pack("<I", 0) + struct.pack("<Q", datalen)
+
+
+def test_query_reproduces_reference_bdb_golden(tmp_path, oracle):
+    """test/bdb/bdb.sh: hermite_cpu_log (dt=0.01, log_interval=0.1, T=1) on test.4.in.txt, then
+    `swarm query -f <binary log>` must print test/bdb/test.4.ref.txt EXACTLY (528 lines).
+    The record stream comes from the oracle (the product has no CPU integrator); the log file
+    reader, the (T, sys) ordering, the Jacobi-coordinate arithmetic and the %9.5lg formatting
+    under test are the product's C++ (`swarm query`)."""
+    O = oracle
+    e = O.load_text(os.path.join(GOLDEN, "bdb", "test.4.in.txt"))
+    log = O.Log(1 << 20)
+    O.integrate(e, O.params("hermite_cpu", 1.0, time_step=0.01), O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), log)
+    raw = tmp_path / "testing_log.bin.raw"
+    raw.write_bytes(swarm_header("unsorted") + log.bytes())
+    ref = open(os.path.join(GOLDEN, "bdb", "test.4.ref.txt")).read()
+    p = run("query", "-f", raw)
+    assert p.stdout == ref
+    assert "# Output in Cartesian coordinates" in p.stderr
+    # ranges: -s 3 -t 0.15..0.45 -b 2..3  (query.hpp:52-92)
+    p = run("query", "-f", raw, "-s", "3", "-t", "0.15..0.45", "-b", "2..3")
+    want = [l for l in ref.splitlines() if int(l.split()[2]) == 3 and 0.15 <= float(l.split()[1]) <= 0.45
+            and int(l.split()[3]) in (2, 3)]
+    # (the reference prints its line break BEFORE every body > 1, so skipping body 1 leaves blank lines)
+    assert [l for l in p.stdout.splitlines() if l] == want and len(want) == 6
+    p = run("query", "-f", raw, "--astrocentric", "-s", "0", "-t", "MIN..0.05")
+    rows = [l.split() for l in p.stdout.splitlines()]
+    assert [int(r[3]) for r in rows] == [0, 1, 2, 3] and [float(x) for x in rows[0][5:11]] == [0.0] * 6
+    p = run("query", check=False)
+    assert p.returncode == 1 and "Name of input log file is missing" in p.stderr
+
+
 # ---------------------------------------------------------------- GPU side
 CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-7)]
 
@@ -141,18 +177,26 @@ def test_benchmark_and_verify_csv():
 
 @pytest.mark.gpu
 def test_log_writers_via_cli(tmp_path, oracle):
-    """hermite_adap_log + log_writer=binary: the raw record stream holds 16 systems x 12 records
-    (t0 + 11 intervals) of 288 bytes for test/bdb/test.4.in.txt"""
+    """C5 path end to end: hermite_adap_log + log_writer=binary (the BDB writer needs libdb, which
+    the image lacks).  The writer leaves a T-sorted binary log file in the reference's format;
+    `swarm query` lists 16 systems x 12 snapshots (t0 + 11 intervals) x 3 planets."""
     O = oracle
-    base = tmp_path / "log"
+    base = tmp_path / "log.bin"
     run("integrate", "-I", os.path.join(GOLDEN, "bdb", "test.4.in.txt"), "integrator=hermite_adap_log",
         "time_step_factor=170e-4", "min_time_step=0.00001", "log_interval=0.1", "destination_time=1",
         "log_writer=binary", "log_output=%s" % base)
-    raw = open(str(base) + ".raw", "rb").read()
-    recs = O.parse_log(raw)
+    assert not os.path.exists(str(base) + ".raw")            # sorted on close, raw file removed
+    blob = open(base, "rb").read()
     e = O.load_text(os.path.join(GOLDEN, "bdb", "test.4.in.txt"))
     olog = O.Log(1 << 20)
     O.integrate(e, O.params("hermite_adap", 1.0, time_step_factor=170e-4, min_time_step=1e-5),
                 O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), olog)
-    assert len(recs) == len(olog.records()) and all(r["len"] == 288 for r in recs)
-    assert (np.bincount([r["sys"] for r in recs]) == np.bincount([r["sys"] for r in olog.records()])).all()
+    assert blob[:96] == swarm_header("sorted", len(olog.bytes()))
+    recs = O.parse_log(blob[96:])
+    orecs = olog.records()
+    assert len(recs) == len(orecs) and all(r["len"] == 288 for r in recs)
+    assert (np.bincount([r["sys"] for r in recs]) == np.bincount([r["sys"] for r in orecs])).all()
+    keys = [(r["time"], r["sys"]) for r in recs]
+    assert keys == sorted(keys)
+    p = run("query", "-f", base)
+    assert len(p.stdout.splitlines()) == 3 * len(orecs)
