@@ -182,6 +182,10 @@ int swarm_hip_memset(void *d_ptr, int value, size_t bytes, void *stream);
 int swarm_hip_memcpy_d2h(void *host, const void *d_ptr, size_t bytes);
 int swarm_hip_memcpy_h2d(void *d_ptr, const void *host, size_t bytes);
 int swarm_hip_synchronize(void *stream);
+/* page-locked host memory for the host side of the event log (gpulog's host buffer is pinned
+ * too: hostAlloc in swarm/log/gpulog/bits/gpulog_log.h); D2H copies into it run at PCIe speed */
+int swarm_hip_host_alloc(void **host_ptr, size_t bytes);
+int swarm_hip_host_free(void *host_ptr);
 /* timing on the launch stream (HIP events): elapsed ms between two marks */
 int swarm_hip_event_create(void **event);
 int swarm_hip_event_record(void *event, void *stream);

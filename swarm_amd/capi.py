@@ -48,7 +48,8 @@ SYMBOLS = [
     "swarm_hip_reactivate", "swarm_hip_total_energy", "swarm_hip_energy_stats",
     "swarm_hip_import_ref_layout", "swarm_hip_export_ref_layout", "swarm_hip_upload_aos",
     "swarm_hip_download_aos", "swarm_hip_malloc", "swarm_hip_free", "swarm_hip_memset",
-    "swarm_hip_memcpy_d2h", "swarm_hip_memcpy_h2d", "swarm_hip_synchronize", "swarm_hip_event_create",
+    "swarm_hip_memcpy_d2h", "swarm_hip_memcpy_h2d", "swarm_hip_synchronize", "swarm_hip_host_alloc",
+    "swarm_hip_host_free", "swarm_hip_event_create",
     "swarm_hip_event_record", "swarm_hip_event_elapsed_ms", "swarm_hip_event_destroy",
 ]
 
@@ -85,6 +86,8 @@ lib.swarm_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
 lib.swarm_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.swarm_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.swarm_hip_synchronize.argtypes = [C.c_void_p]
+lib.swarm_hip_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+lib.swarm_hip_host_free.argtypes = [C.c_void_p]
 lib.swarm_hip_event_create.argtypes = [C.POINTER(C.c_void_p)]
 lib.swarm_hip_event_record.argtypes = [C.c_void_p, C.c_void_p]
 lib.swarm_hip_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

@@ -584,6 +584,20 @@ int swarm_hip_memcpy_h2d(void *d_ptr, const void *host, size_t bytes) {
     if (bytes) HIP_TRY(hipMemcpy(d_ptr, host, bytes, hipMemcpyHostToDevice));
     return SWARM_HIP_OK;
 }
+int swarm_hip_host_alloc(void **host_ptr, size_t bytes) {
+    if (!host_ptr) {
+        set_error("host_alloc: NULL out pointer");
+        return SWARM_HIP_EINVAL;
+    }
+    *host_ptr = nullptr;
+    if (bytes == 0) return SWARM_HIP_OK;
+    HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_host_free(void *host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return SWARM_HIP_OK;
+}
 int swarm_hip_synchronize(void *stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return SWARM_HIP_OK;

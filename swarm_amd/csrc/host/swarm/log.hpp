@@ -55,10 +55,10 @@ class manager {
     uint8_t *d_buf;
     int32_t *d_cursor;
     int capacity;
-    std::vector<uint8_t> host;
+    uint8_t *host; // pinned, `capacity` bytes
     long long _dropped;
 public:
-    manager() : d_buf(0), d_cursor(0), capacity(0), _dropped(0) {}
+    manager() : d_buf(0), d_cursor(0), capacity(0), host(0), _dropped(0) {}
     ~manager();
     // default 50 MiB each, logmanager.hpp:67
     void init(const config &cfg, int host_buffer_size = 50 * 1024 * 1024, int device_buffer_size = 50 * 1024 * 1024);

@@ -85,6 +85,7 @@ static writer_plugin_initializer<binary_writer> binary_writer_plugin("binary", "
 manager::~manager() {
     if (d_buf) swarm_hip_free(d_buf);
     if (d_cursor) swarm_hip_free(d_cursor);
+    if (host) swarm_hip_host_free(host);
 }
 void manager::init(const config &cfg, int, int device_buffer_size) {
     log_writer.reset(writer::create(cfg));
@@ -92,6 +93,7 @@ void manager::init(const config &cfg, int, int device_buffer_size) {
     capacity = device_buffer_size;
     hipErrCheck(swarm_hip_malloc((void **)&d_buf, (size_t)capacity));
     hipErrCheck(swarm_hip_malloc((void **)&d_cursor, 8));
+    hipErrCheck(swarm_hip_host_alloc((void **)&host, (size_t)capacity));
     hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));
     hipErrCheck(swarm_hip_synchronize(0));
 }
@@ -111,9 +113,8 @@ void manager::flush() {
     hipErrCheck(swarm_hip_memcpy_d2h(cur, d_cursor, 8));
     _dropped += cur[1];
     if (cur[0] > 0) {
-        host.resize((size_t)cur[0]);
-        hipErrCheck(swarm_hip_memcpy_d2h(host.data(), d_buf, (size_t)cur[0]));
-        log_writer->process((const char *)host.data(), host.size());
+        hipErrCheck(swarm_hip_memcpy_d2h(host, d_buf, (size_t)cur[0]));
+        log_writer->process((const char *)host, (size_t)cur[0]);
     }
     if (cur[0] || cur[1]) {
         hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));

@@ -20,9 +20,11 @@ WORKLOADS = {
                cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27",
                     "deactivate_on_ejection": "1", "rmax": "1000"}),
     "c4": dict(integrator="mvs", nsys=131072, nbod=8, T=10.0, cfg={"time_step": "0.01"}),  # one 1/8 shard of 2^20
-    "c5": dict(integrator="hermite_adap_log", nsys=65536, nbod=4, T=1.0,
-               cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001", "log_interval": "0.1"}, log=400 << 20),
-    "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=1.0,
+    # Hermite_Adaptive.cfg + log_time_interval; T=100 (~270 adaptive steps per system), one snapshot
+    # per system every 5 time units => 21 records x 288 B x 65536 = 396 MB of log per run
+    "c5": dict(integrator="hermite_adap_log", nsys=65536, nbod=4, T=100.0,
+               cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001", "log_interval": "5"}, log=420 << 20),
+    "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
                      cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
 }
 
@@ -57,7 +59,7 @@ def main():
             integ.args.block_size = a.block
         lm = None
         if w.get("log"):
-            lm = S.LogManager(w["log"], "host")
+            lm = S.LogManager(w["log"], "count")
             integ.set_log_manager(lm)
         integ.enable_step_counters()
         integ.upload_ensemble()
@@ -65,15 +67,22 @@ def main():
         L.swarm_hip_event_create(C.byref(e0)); L.swarm_hip_event_create(C.byref(e1))
         L.swarm_hip_event_record(e0, None)
         t0 = time.perf_counter()
-        attempts = integ.core_integrate()
+        integ.launch_integrator()
         L.swarm_hip_event_record(e1, None)
+        L.swarm_hip_synchronize(None)
+        tk = time.perf_counter()
+        integ.flush_log()
+        tf = time.perf_counter()
+        attempts = 1
+        if integ._dens.count_active() != 0:
+            attempts += integ.core_integrate()
         ms = C.c_float()
         L.swarm_hip_event_elapsed_ms(e0, e1, C.byref(ms))
         wall = time.perf_counter() - t0
         acc, att = integ.step_counts()
         integ.download_ensemble()
         res.append(dict(ms=ms.value, wall_ms=wall * 1e3, accepted=int(acc.sum()), attempted=int(att.sum()),
-                        attempts=attempts, log_bytes=len(lm.host) if lm else 0, dropped=lm.dropped if lm else 0,
+                        attempts=attempts, flush_ms=(tf - tk) * 1e3, log_bytes=lm.bytes_flushed if lm else 0, dropped=lm.dropped if lm else 0,
                         states={int(k): int(v) for k, v in zip(*np.unique(host.state, return_counts=True))}))
     best = min(res, key=lambda r: r["ms"])
     out = dict(workload=a.workload, integrator=w["integrator"], nsys=nsys, nbod=nbod, T=T, **best)
