@@ -51,7 +51,8 @@ enum swarm_hip_integrator {
     SWARM_HIP_MVS = 5,           /* plugins/mvs.cu:37, propagators/mvs.hpp + keplerian.hpp */
     SWARM_HIP_EULER = 6,         /* plugins/euler.cu:36, propagators/euler.hpp */
     SWARM_HIP_VERLET = 7,        /* plugins/verlet.cu:35, propagators/verlet.hpp */
-    SWARM_HIP_MIDPOINT = 8       /* plugins/midpoint.cu:35, propagators/midpoint.hpp */
+    SWARM_HIP_MIDPOINT = 8,      /* plugins/midpoint.cu:35, propagators/midpoint.hpp */
+    SWARM_HIP_HERMITE_PROP = 9   /* plugins/hermite_prop.cu:37, propagators/hermite_propagator.hpp */
 };
 
 /* monitor bound to the plugin name */
@@ -90,7 +91,7 @@ typedef struct swarm_hip_launch {
     int32_t block_size;     /* threads per workgroup, multiple of 64; 0 = default;
                                the analogue of system_per_block=                          */
     double destination_time; /*                                   destination_time=      */
-    double time_step;        /* hermite, mvs, euler, midpoint     time_step=             */
+    double time_step;        /* hermite(_prop), mvs, euler, midpoint time_step=          */
     double time_step_factor; /* hermite_adap                      time_step_factor=      */
     double min_time_step;    /* hermite_adap, rkck                min_time_step=         */
     double max_time_step;    /* rkck                              max_time_step=         */

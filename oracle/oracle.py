@@ -16,7 +16,7 @@ ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE = 0, 1, 2
 INTEGRATORS = {
     "hermite_cpu": 0, "hermite": 1, "hermite_adap": 2, "rkck_fixed": 3, "rkck_adaptive": 4,
-    "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8,
+    "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9,
 }
 FLT_MAX = float(np.finfo(np.float32).max)
 

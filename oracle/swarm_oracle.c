@@ -780,6 +780,8 @@ static void generic_system(sysref s, const orc_params *P, const orc_monitor *M, 
     } else if (kind == ORC_INT_VERLET) {
         gpu_acc_pairs(&s, sa);
     }
+    double hacc0[NB][3], hjerk0[NB][3]; /* HermitePropagator::init, hermite_propagator.hpp:77-82 */
+    if (kind == ORC_INT_HERMITE_PROP) gpu_accjerk(&s, hacc0, hjerk0);
 #define VERLET_TIMESTEP()                                                                  \
     do { /* verlet.hpp:112-137; one_over_r = sum of squares of shared acc (gravitation_acc.hpp:78-93) */ \
         double factor = 0.;                                                                \
@@ -823,6 +825,30 @@ static void generic_system(sysref s, const orc_params *P, const orc_monitor *M, 
                 for (int c = 0; c < 3; c++) s.vel[b][c] += hby2 * acc_bc[b][c];
             mvs_drift(&s, hby2);
             *s.time += 2.0 * hby2;
+        } else if (kind == ORC_INT_HERMITE_PROP) { /* hermite_propagator.hpp:106-142 */
+            double h = fmin(P->time_step, max_timestep);
+            double pre_pos[NB][3], pre_vel[NB][3], acc1[NB][3], jerk1[NB][3];
+            for (int b = 0; b < nbod; b++)
+                for (int c = 0; c < 3; c++) {
+                    double pos = s.pos[b][c], vel = s.vel[b][c];
+                    pos = pos + h * (vel + (h * 0.5) * (hacc0[b][c] + (h / 3.0) * hjerk0[b][c]));
+                    vel = vel + h * (hacc0[b][c] + (h * 0.5) * hjerk0[b][c]);
+                    pre_pos[b][c] = s.pos[b][c] = pos;
+                    pre_vel[b][c] = s.vel[b][c] = vel;
+                }
+            for (int i = 0; i < 2; i++) {
+                gpu_accjerk(&s, acc1, jerk1);
+                for (int b = 0; b < nbod; b++)
+                    for (int c = 0; c < 3; c++) {
+                        s.pos[b][c] = pre_pos[b][c] + ((0.1 - 0.25) * (hacc0[b][c] - acc1[b][c]) -
+                                                       1.0 / 60.0 * (7.0 * hjerk0[b][c] + 2.0 * jerk1[b][c]) * h) * h * h;
+                        s.vel[b][c] = pre_vel[b][c] + ((-0.5) * (hacc0[b][c] - acc1[b][c]) -
+                                                       1.0 / 12.0 * (5.0 * hjerk0[b][c] + jerk1[b][c]) * h) * h;
+                    }
+            }
+            memcpy(hacc0, acc1, sizeof(double) * 3 * nbod);
+            memcpy(hjerk0, jerk1, sizeof(double) * 3 * nbod);
+            *s.time += h;
         } else if (kind == ORC_INT_EULER) {
             double h = fmin(P->time_step, max_timestep);
             const double third = 1.0 / 3.0;

@@ -65,7 +65,8 @@ enum {
     ORC_INT_MVS = 5,
     ORC_INT_EULER = 6,
     ORC_INT_VERLET = 7,
-    ORC_INT_MIDPOINT = 8
+    ORC_INT_MIDPOINT = 8,
+    ORC_INT_HERMITE_PROP = 9 /* propagators/hermite_propagator.hpp under generic<> */
 };
 
 typedef struct {

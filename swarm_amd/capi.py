@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libswarm_hip.so")
 CHUNK = 64
 MIN_NBOD, MAX_NBOD = 3, 8
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
-HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT = range(1, 9)
+HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP = range(1, 10)
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE = 0, 1, 2
 
 

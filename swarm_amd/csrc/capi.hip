@@ -333,6 +333,7 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
 
     switch (a->integrator) {
     case SWARM_HIP_HERMITE:
+    case SWARM_HIP_HERMITE_PROP:
     case SWARM_HIP_EULER:
     case SWARM_HIP_MIDPOINT:
     case SWARM_HIP_MVS:
@@ -370,6 +371,7 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     case SWARM_HIP_EULER:
     case SWARM_HIP_VERLET:
     case SWARM_HIP_MIDPOINT:
+    case SWARM_HIP_HERMITE_PROP:
         return launch_generic(c, a->integrator);
     default:
         set_error("unknown integrator id %d", a->integrator);

@@ -239,7 +239,8 @@ public:
         a.monitor = MON;
         int spb = cfg.optional("system_per_block", 0); // the reference's block-shape knob
         if (spb > 0) a.block_size = std::max(64, std::min(256, (spb + 63) / 64 * 64));
-        if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_MVS || ID == SWARM_HIP_EULER || ID == SWARM_HIP_MIDPOINT)
+        if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_MVS || ID == SWARM_HIP_EULER || ID == SWARM_HIP_MIDPOINT ||
+            ID == SWARM_HIP_HERMITE_PROP)
             a.time_step = cfg.require("time_step", 0.0); // hermite_integrator.hpp:44-46, mvs.hpp:41-43, ...
         if (ID == SWARM_HIP_HERMITE_ADAP) { // hermite_adap.hpp:44-47
             a.time_step_factor = cfg.require("time_step_factor", 0.0);
@@ -300,6 +301,7 @@ REG(p_mvs_ce, SWARM_HIP_MVS, SWARM_HIP_MON_EJECTION_OR_CLOSE, "mvs_close_encount
 REG(p_euler, SWARM_HIP_EULER, SWARM_HIP_MON_EJECTION, "euler", "This is the integrator based on euler propagator");
 REG(p_verlet, SWARM_HIP_VERLET, SWARM_HIP_MON_EJECTION, "verlet", "This is the integrator based on verlet propagator");
 REG(p_midpoint, SWARM_HIP_MIDPOINT, SWARM_HIP_MON_EJECTION, "midpoint", "This is the integrator based on midpoint propagator");
+REG(p_hermite_prop, SWARM_HIP_HERMITE_PROP, SWARM_HIP_MON_EJECTION, "hermite_prop", "Propagator version of Hermite integrator");
 
 // ---- swarm::init -----------------------------------------------------------------------------
 void init(const config &cfg) {

@@ -1,4 +1,5 @@
-// kernels_generic.hip -- propagator kernels: MVS, Euler(3rd-order Taylor), Verlet, Midpoint.
+// kernels_generic.hip -- propagator kernels: MVS, Euler(3rd-order Taylor), Verlet, Midpoint,
+// Hermite-as-propagator.
 //
 // Replaces generic<Propagator,Monitor,Gravitation>::kernel
 // (swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238) and the propagators
@@ -208,6 +209,13 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
         } else if (KIND == SWARM_HIP_VERLET) {
             timestep = verlet_timestep(s, ip);
         }
+        // HermitePropagator::init, hermite_propagator.hpp:77-82: (acc0, jerk0) carried across steps
+        double hj[N][3], ha1[N][3], hj1[N][3];
+        StepConsts hk;
+        if (KIND == SWARM_HIP_HERMITE_PROP) {
+            accjerk<N>(s.p, s.v, s.m, acc, hj);
+            hk.set(ip.time_step);
+        }
 
         for (int iter = 0; iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; iter++) {
             double max_timestep;
@@ -231,6 +239,15 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
                     for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
                 mvs_drift(s, hby2);
                 s.t += 2.0 * hby2;
+            } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
+                const double h = fmin(ip.time_step, max_timestep);
+                if (h != hk.h) hk.set(h);
+                hermite_step<N>(s, hk, acc, hj, ha1, hj1);
+#pragma unroll
+                for (int b = 0; b < N; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[b][c] = ha1[b][c], hj[b][c] = hj1[b][c];
+                s.t += h;
             } else if (KIND == SWARM_HIP_EULER) { // EulerPropagator::advance, euler.hpp:101-122
                 const double h = fmin(ip.time_step, max_timestep);
                 const double third = 1.0 / 3.0;
@@ -357,6 +374,9 @@ int launch_generic(const LaunchCtx &c, int integrator) {
         break;
     case SWARM_HIP_MIDPOINT:
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MIDPOINT>(c)));
+        break;
+    case SWARM_HIP_HERMITE_PROP:
+        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_HERMITE_PROP>(c)));
         break;
     default:
         set_error("unknown propagator id %d", integrator);

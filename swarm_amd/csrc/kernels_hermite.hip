@@ -8,65 +8,6 @@
 
 namespace swh {
 
-// Per-step constants that depend only on h.  For the fixed-step integrator h changes at most once
-// per launch (the clipped last step), so they are recomputed only when h changes.
-struct StepConsts {
-    double h, hh, h3;        // h, h*0.5, h/3.0             (predictor, hermite_integrator.hpp:131-132)
-    double kp_a, kp_j0, kp_j1; // position corrector weights  (L146)
-    double kv_a, kv_j0, kv_j1; // velocity corrector weights  (L147)
-    __device__ __forceinline__ void set(double h_) {
-        h = h_;
-        hh = h_ * 0.5;
-        h3 = h_ / 3.0;
-        const double h2 = h_ * h_;
-        const double c60 = (1.0 / 60.0) * h_, c12 = (1.0 / 12.0) * h_;
-        // pos = pre + ((0.1-0.25)*(a0-a1) - 1/60*(7 j0 + 2 j1) h) h^2, expanded per operand
-        kp_a = (0.1 - 0.25) * h2;
-        kp_j0 = -(7.0 * c60) * h2;
-        kp_j1 = -(2.0 * c60) * h2;
-        // vel = pre + ((-0.5)*(a0-a1) - 1/12*(5 j0 + j1) h) h
-        kv_a = (-0.5) * h_;
-        kv_j0 = -(5.0 * c12) * h_;
-        kv_j1 = -c12 * h_;
-    }
-};
-
-// One PEC2 Hermite step on register-resident state: predictor, 2 x (force + corrector).
-// (a0,j0) = forces at the start of the step, (a1,j1) receive the forces at the end; the caller
-// alternates the two buffer pairs so no copy `acc0 = acc1` (hermite_integrator.hpp:163) is needed.
-// The corrector is the reference's factored form expanded per operand: the terms in a0,j0 are
-// summed once per step (c0,d0), each round adds the a1,j1 terms and makes ONE rounding at the
-// magnitude of pos/vel, like the reference's final `pre_pos + (...)`.
-template <int N>
-__device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
-                                             const double (&j0)[N][3], double (&a1)[N][3],
-                                             double (&j1)[N][3]) {
-    double pp[N][3], pv[N][3], c0[N][3], d0[N][3];
-#pragma unroll
-    for (int b = 0; b < N; b++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            pp[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[b][c], a0[b][c]), s.v[b][c]),
-                                     s.p[b][c]);
-            pv[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[b][c], a0[b][c]), s.v[b][c]);
-            c0[b][c] = __builtin_fma(k.kp_a, a0[b][c], k.kp_j0 * j0[b][c]);
-            d0[b][c] = __builtin_fma(k.kv_a, a0[b][c], k.kv_j0 * j0[b][c]);
-            s.p[b][c] = pp[b][c];
-            s.v[b][c] = pv[b][c];
-        }
-#pragma unroll
-    for (int round = 0; round < 2; round++) {
-        accjerk<N>(s.p, s.v, s.m, a1, j1);
-#pragma unroll
-        for (int b = 0; b < N; b++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                s.p[b][c] = pp[b][c] + __builtin_fma(-k.kp_a, a1[b][c], __builtin_fma(k.kp_j1, j1[b][c], c0[b][c]));
-                s.v[b][c] = pv[b][c] + __builtin_fma(-k.kv_a, a1[b][c], __builtin_fma(k.kv_j1, j1[b][c], d0[b][c]));
-            }
-    }
-}
-
 template <int N, bool ADAPTIVE, bool MON>
 __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {

@@ -40,6 +40,7 @@ PLUGINS = {
     "integrator_euler": (capi.EULER, capi.MON_EJECTION),
     "integrator_verlet": (capi.VERLET, capi.MON_EJECTION),
     "integrator_midpoint": (capi.MIDPOINT, capi.MON_EJECTION),
+    "integrator_hermite_prop": (capi.HERMITE_PROP, capi.MON_EJECTION),
 }
 
 
@@ -144,7 +145,7 @@ class GpuIntegrator(Integrator):
         if spb:
             a.block_size = max(64, min(256, (spb + 63) // 64 * 64))
         # constructor-time key checks follow each reference ctor
-        if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT):
+        if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT, capi.HERMITE_PROP):
             a.time_step = cfg.require("time_step", 0.0)      # hermite_integrator.hpp:44-46 etc.
         if self.int_id == capi.HERMITE_ADAP:
             a.time_step_factor = cfg.require("time_step_factor", 0.0)  # hermite_adap.hpp:45-46

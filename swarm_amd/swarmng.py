@@ -1,0 +1,220 @@
+"""`swarmng`-compatible Python surface (py/swarmng/__init__.py + src/python/module.cpp:181-294 of
+the reference, which needs boost.python and Python 2): the same names and call shapes over this
+package's ctypes binding, so scripts like py/tests/trivial.py run with `import swarm_amd.swarmng as
+swarmng`.  Ensembles are views onto HostEnsemble's numpy arrays."""
+import math
+
+import numpy as np
+
+from . import capi
+from . import snapshot as _snap
+from .config import config as _config
+from .ensemble import HostEnsemble
+from .ensemble import generate_ensemble as _generate
+from .integrator import GpuIntegrator as _GpuIntegrator
+from .integrator import Integrator as _Integrator
+from .integrator import LogManager
+
+
+def init(cfg):
+    """swarm::init(cfg), swarm/swarm.h:49"""
+    capi.check(capi.lib.swarm_hip_init(cfg.optional("HIP_DEVICE", cfg.optional("CUDA_DEVICE", 0))))
+
+
+def sync():
+    capi.check(capi.lib.swarm_hip_synchronize(None))
+
+
+class Config(_config):
+    @staticmethod
+    def load(path, initial=None):
+        return Config(_config.load(path, initial))
+
+
+def config(*l, **kw):
+    """swarmng.config(dict..., key=value...) -> Config with stringified values (__init__.py:77-105)"""
+    c = Config()
+    for h in list(l) + [kw]:
+        for k, v in h.items():
+            c[str(k)] = str(v)
+    return c
+
+
+mkConfig = config
+
+
+class _Attributes:
+    def __init__(self, arr):
+        self._a = arr
+
+    def __len__(self):
+        return len(self._a)
+
+    def __getitem__(self, i):
+        return float(self._a[i])
+
+    def __setitem__(self, i, v):
+        self._a[i] = v
+
+
+class _Component:
+    def __init__(self, e, i, b, c):
+        self._e, self._k = e, (i, b, c)
+
+    pos = property(lambda s: float(s._e.pos[s._k]), lambda s, v: s._e.pos.__setitem__(s._k, v))
+    vel = property(lambda s: float(s._e.vel[s._k]), lambda s, v: s._e.vel.__setitem__(s._k, v))
+
+
+class Body:
+    def __init__(self, e, i, b):
+        self._e, self._i, self._b = e, i, b
+
+    mass = property(lambda s: float(s._e.mass[s._i, s._b]), lambda s, v: s._e.mass.__setitem__((s._i, s._b), v))
+    pos = property(lambda s: [float(x) for x in s._e.pos[s._i, s._b]],
+                   lambda s, v: s._e.pos.__setitem__((s._i, s._b), v))
+    vel = property(lambda s: [float(x) for x in s._e.vel[s._i, s._b]],
+                   lambda s, v: s._e.vel.__setitem__((s._i, s._b), v))
+    attributes = property(lambda s: _Attributes(s._e.body_attr[s._i, s._b]))
+
+    def distance_to_origin(self):
+        return math.sqrt(float((self._e.pos[self._i, self._b] ** 2).sum()))
+
+    def speed(self):
+        return math.sqrt(float((self._e.vel[self._i, self._b] ** 2).sum()))
+
+    def __getitem__(self, c):
+        if not 0 <= c < 3:
+            raise IndexError("")
+        return _Component(self._e, self._i, self._b, c)
+
+
+class System:
+    def __init__(self, e, i):
+        self._e, self._i = e, i
+
+    def __len__(self):
+        return self._e.nbod
+
+    def __getitem__(self, b):
+        if not 0 <= b < self._e.nbod:
+            raise IndexError("")
+        return Body(self._e, self._i, b)
+
+    time = property(lambda s: float(s._e.time[s._i]), lambda s, v: s._e.time.__setitem__(s._i, v))
+    id = property(lambda s: int(s._e.id[s._i]), lambda s, v: s._e.id.__setitem__(s._i, v))
+    state = property(lambda s: int(s._e.state[s._i]), lambda s, v: s._e.state.__setitem__(s._i, v))
+    attributes = property(lambda s: _Attributes(s._e.sys_attr[s._i]))
+    total_energy = property(lambda s: float(s._e.slice(s._i, s._i + 1).calc_total_energy()[0]))
+
+    def is_active(self):
+        return self.state == capi.ACTIVE
+
+    def is_inactive(self):
+        return self.state == capi.INACTIVE
+
+    def is_enabled(self):
+        return self.state != capi.DISABLED
+
+    def set_active(self):
+        self.state = capi.ACTIVE
+
+    def set_inactive(self):
+        self.state = capi.INACTIVE
+
+    def set_disabled(self):
+        self.state = capi.DISABLED
+
+
+class DefaultEnsemble(HostEnsemble):
+    """swarm::defaultEnsemble as exported to Python (module.cpp:246-257)"""
+
+    @staticmethod
+    def create(nbod, nsys):
+        return DefaultEnsemble(nsys, nbod)
+
+    @staticmethod
+    def _wrap(h):
+        e = DefaultEnsemble(h.nsys, h.nbod, h.nbattr, h.nsattr)
+        for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
+            setattr(e, k, getattr(h, k))
+        return e
+
+    def clone(self):
+        return DefaultEnsemble._wrap(HostEnsemble.clone(self))
+
+    def __len__(self):
+        return self.nsys
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.nsys:
+            raise IndexError("")
+        return System(self, i)
+
+    def save_to_text(self, fn):
+        _snap.save_text(self, fn)
+
+    def save_to_bin(self, fn):
+        _snap.save(self, fn)
+
+    @staticmethod
+    def load_from_text(fn):
+        return DefaultEnsemble._wrap(_snap.load_text(fn))
+
+    @staticmethod
+    def load_from_bin(fn):
+        return DefaultEnsemble._wrap(_snap.load(fn))
+
+
+Ensemble = DefaultEnsemble
+
+
+def generate_ensemble(cfg):
+    return DefaultEnsemble._wrap(_generate(cfg))
+
+
+class Integrator:
+    """swarmng.Integrator: create(cfg), .ensemble, .destination_time, .integrate()"""
+
+    def __init__(self, impl):
+        self._impl = impl
+
+    @staticmethod
+    def create(cfg):
+        return GpuIntegrator(_Integrator.create(cfg))
+
+    def integrate(self):
+        self._impl.integrate()
+
+    def _get_ens(self):
+        return self._impl.get_ensemble()
+
+    def _set_ens(self, e):
+        self._impl.set_ensemble(e)
+
+    ensemble = property(_get_ens, _set_ens)
+    destination_time = property(lambda s: s._impl.get_destination_time(),
+                                lambda s, t: s._impl.set_destination_time(t))
+
+
+class GpuIntegrator(Integrator):
+    @staticmethod
+    def create(cfg):
+        return GpuIntegrator(_Integrator.create(cfg))
+
+    def core_integrate(self):
+        return self._impl.core_integrate()
+
+    def upload_ensemble(self):
+        self._impl.upload_ensemble()
+
+    def download_ensemble(self):
+        self._impl.download_ensemble()
+
+    def set_log_manager(self, lm):
+        self._impl.set_log_manager(lm)
+
+
+def find_max_energy_conservation_error(ens, reference_ensemble):
+    """swarm/utils.cpp:105-121"""
+    e0, e1 = reference_ensemble.calc_total_energy(), ens.calc_total_energy()
+    return float(np.abs((e1 - e0) / e0).max())

@@ -75,7 +75,7 @@ def test_config_semantics(tmp_path):
 def test_plugin_registry_names_and_errors():
     import swarm_amd as S
     for name in ("hermite", "hermite_adap", "hermite_adap_log", "rkck_fixed", "rkck_adaptive", "mvs", "verlet",
-                 "euler", "midpoint", "hermite_adap_close_encounter", "mvs_close_encounter"):
+                 "euler", "midpoint", "hermite_adap_close_encounter", "mvs_close_encounter", "hermite_prop"):
         assert "integrator_" + name in S.PLUGINS
     with pytest.raises(S.runtime_error, match="Integrator hermite_log not found"):
         S.Integrator.create(S.config({"integrator": "hermite_log"}))      # commented out in the fork

@@ -26,6 +26,7 @@ CASES = {
     "midpoint": ({"time_step": "1e-4"}, dict(time_step=1e-4), 1.0),
     "verlet": ({"max_timestep": "1e-4", "timestep_scale": "1.0"}, dict(max_timestep=1e-4, timestep_scale=1.0), 1.0),
     "mvs": ({"time_step": "0.01"}, dict(time_step=0.01), 1.0),
+    "hermite_prop": ({"time_step": "0.003"}, dict(time_step=0.003), 1.0),
 }
 
 
@@ -57,7 +58,7 @@ def test_integrator_vs_oracle(gpu, oracle, name, nbod):
     assert rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
     assert np.abs(h.pos[:, 0] - e.pos[:, 0]).max() < TOL and np.abs(h.vel[:, 0] - e.vel[:, 0]).max() < TOL
     gacc, gatt = integ.step_counts()
-    if name in ("euler", "midpoint", "mvs", "rkck_fixed"):
+    if name in ("euler", "midpoint", "mvs", "rkck_fixed", "hermite_prop"):
         # fixed step: identical h sequence -> identical step counts and bit-identical times
         assert (gacc == acc.astype(np.uint64)).all() and (gatt == att.astype(np.uint64)).all()
         assert (h.time == e.time).all()

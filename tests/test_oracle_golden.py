@@ -48,6 +48,7 @@ CFGS = {
     "rkck_fixed": dict(min_time_step=1e-4, max_time_step=1e-4, error_tolerance=1e-27),
     "euler": dict(time_step=1e-5),
     "midpoint": dict(time_step=1e-5),
+    "hermite_prop": dict(time_step=0.01),     # samples/Hermite_Prop.cfg family
 }
 
 

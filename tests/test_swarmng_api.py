@@ -1,0 +1,144 @@
+"""The reference's Python unit tests (py/tests/trivial.py + abstract.py) against the
+swarmng-compatible module.  The reference runs them with integrator=hermite_cpu (nogpu=1); this
+build has no CPU integrators, so the same scenarios run the GPU `hermite` plugin."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+
+def fill(list_like, initial_value):
+    for i in range(0, len(list_like)):
+        list_like[i] = initial_value
+
+
+def make_test_case(swarmng, nsys=16, nbod=3, spacing_factor=1.4, planet_mass=0.001, ejection_factor=1, seed=None):
+    """py/tests/trivial.py:18-42, verbatim semantics"""
+    random.seed(seed)
+    d = swarmng.DefaultEnsemble.create(nbod, nsys)
+    for i in range(0, d.nsys):
+        s = d[i]
+        s.id = i
+        s.set_active()
+        s.time = 0
+        s[0].pos = [0, 0, 0]
+        s[0].vel = [0, 0, 0]
+        s[0].mass = 1
+        fill(s.attributes, 0)
+        for j in range(0, d.nbod):
+            fill(s[j].attributes, 0)
+        for j in range(1, d.nbod):
+            r = spacing_factor ** (j - 1)
+            v = math.sqrt(1 / r) * ejection_factor
+            phi = random.uniform(0, 2 * math.pi)
+            s[j].pos = [r * math.cos(phi), r * math.sin(phi), 0]
+            s[j].vel = [-v * math.sin(phi), v * math.cos(phi), 0]
+            s[j].mass = planet_mass
+    return d
+
+
+def test_api_surface_without_gpu(tmp_path):
+    import swarm_amd.swarmng as swarmng
+    cfg = swarmng.config({"nsys": 4}, nbod=3, integrator="hermite", time_step=1e-3)
+    assert cfg["nsys"] == "4" and cfg["time_step"] == "0.001"
+    e = swarmng.generate_ensemble(cfg)
+    assert len(e) == 4 and e.nbod == 3 and len(e[0]) == 3
+    s = e[1]
+    assert s.is_active() and s.id == 1 and s[0].mass == 1.0 and s[1].distance_to_origin() == pytest.approx(10.0)
+    s[2][0].pos = 3.5
+    assert e.pos[1, 2, 0] == 3.5 and s[2].pos[0] == 3.5
+    s.set_disabled()
+    assert s.state == -1 and not s.is_enabled()
+    with pytest.raises(IndexError):
+        e[4]
+    c = e.clone()
+    c[0].time = 7.0
+    assert e[0].time == 0.0
+    e.save_to_text(str(tmp_path / "a.txt"))
+    e.save_to_bin(str(tmp_path / "a.bin"))
+    a, b = swarmng.DefaultEnsemble.load_from_text(str(tmp_path / "a.txt")), swarmng.DefaultEnsemble.load_from_bin(str(tmp_path / "a.bin"))
+    assert (b.pos == e.pos).all() and (b.state == e.state).all() and (b.body_attr == e.body_attr).all()
+    assert np.abs(a.pos - e.pos).max() < 1e-14 and (a.state == e.state).all()
+    assert swarmng.find_max_energy_conservation_error(b, e) == 0.0
+    assert e[0].total_energy == pytest.approx(e.calc_total_energy()[0])
+
+
+def test_snapshot_files_interoperate_with_cli_and_reference_fixtures(tmp_path, oracle):
+    """python text/binary I/O reads the reference's fixture and the C++ CLI's binary output"""
+    import os
+    import subprocess
+    import swarm_amd.swarmng as swarmng
+    from conftest import GOLDEN, ROOT
+    src = os.path.join(GOLDEN, "integrators", "test.4.out.txt")
+    a = swarmng.DefaultEnsemble.load_from_text(src)
+    o = oracle.load_text(src)
+    for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr"):
+        assert (getattr(a, k) == getattr(o, k)).all(), k
+    binf = str(tmp_path / "c.bin")
+    subprocess.check_call([os.path.join(ROOT, "swarm_amd", "bin", "swarm"), "convert", "-I", src, "-o", binf])
+    b = swarmng.DefaultEnsemble.load_from_bin(binf)
+    assert (b.pos == a.pos).all() and (b.vel == a.vel).all() and (b.id == a.id).all()
+    a.save_to_bin(str(tmp_path / "p.bin"))
+    assert open(str(tmp_path / "p.bin"), "rb").read() == open(binf, "rb").read()
+
+
+class _IntegrationTest:
+    """py/tests/abstract.py IntegrationTest: create ensemble, keep a reference copy, integrate, examine"""
+    destination_time = 10.0
+
+    def run(self, swarmng):
+        self.ens = self.createEnsemble(swarmng)
+        self.ref = self.ens.clone()
+        swarmng.init(self.cfg(swarmng))
+        integ = swarmng.Integrator.create(self.cfg(swarmng))
+        integ.ensemble = self.ens
+        integ.destination_time = self.destination_time
+        integ.integrate()
+        swarmng.sync()
+        self.examine(swarmng)
+
+
+@pytest.mark.gpu
+def test_basic_integration_energy_conservation():
+    """trivial.py:89-99: dt=1e-4, T=10, nsys=16, nbod=3 -> max |dE/E| < 1e-13"""
+    import swarm_amd.swarmng as swarmng
+
+    class T(_IntegrationTest):
+        def cfg(self, sw):
+            return sw.config(integrator="hermite", time_step=1e-4)
+
+        def createEnsemble(self, sw):
+            return make_test_case(sw, nsys=16, nbod=3, spacing_factor=1.4, seed=14321)
+
+        def examine(self, sw):
+            assert sw.find_max_energy_conservation_error(self.ens, self.ref) < 1e-13
+            assert all(s.state == 1 and s.time == pytest.approx(10.0, rel=1e-12) for s in self.ens)
+    T().run(swarmng)
+
+
+@pytest.mark.gpu
+def test_ejection_test():
+    """trivial.py:111-129: dt=1e-3, deactivate_on_ejection=1, rmax=10, T=100, nsys=20 nbod=6,
+    spacing 1.01: any body with r > rmax => its system is disabled (state == -1)"""
+    import swarm_amd.swarmng as swarmng
+    RMAX = 10
+
+    class T(_IntegrationTest):
+        destination_time = 100
+
+        def cfg(self, sw):
+            return sw.config(integrator="hermite", time_step=1e-3, deactivate_on_ejection=1, rmax=RMAX)
+
+        def createEnsemble(self, sw):
+            return make_test_case(sw, nsys=20, nbod=6, spacing_factor=1.01, seed=99)
+
+        def examine(self, sw):
+            n_ejected = 0
+            for s in self.ens:
+                for b in s:
+                    if b.distance_to_origin() > RMAX:
+                        n_ejected += 1
+                        assert s.state == -1, "a system with an ejected body should be disabled"
+            assert sum(1 for s in self.ens if s.state == -1) > 0 or n_ejected == 0
+    T().run(swarmng)
