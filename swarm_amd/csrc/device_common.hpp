@@ -226,9 +226,15 @@ struct StepConsts {
 // One PEC2 Hermite step on register-resident state: predictor, 2 x (force + corrector).
 // (a0,j0) = forces at the start of the step, (a1,j1) receive the forces at the end; the caller
 // alternates the two buffer pairs so no copy `acc0 = acc1` (hermite_integrator.hpp:163) is needed.
-// The corrector is the reference's factored form expanded per operand: the terms in a0,j0 are
-// summed once per step (c0,d0), each round adds the a1,j1 terms and makes ONE rounding at the
-// magnitude of pos/vel, like the reference's final `pre_pos + (...)`.
+// The corrector is expanded per operand, with the a0,j0 terms formed once per step.
+// POSITION follows hermite_cpu's un-factored form `pre_pos + c1*(a0-a1)*h*h - c2*(7 j0+2 j1)*h*h*h`
+// (integrators/hermite_cpu.hpp:152-158): the acceleration part and the jerk part are added to
+// pre_pos SEPARATELY.  They cancel to O(h^4), i.e. far below one ulp of pos for small h, so the
+// CUDA kernel's factored form `pre_pos + (A - B)` (hermite_integrator.hpp:146) always rounds the
+// net correction away (stagnation): measured with the oracle at dt=1e-4, r=1, 1e5 steps it
+// drifts 6.6e-12 in position and conserves energy 10x worse (5.8e-13 vs 4.1e-14) than
+// hermite_cpu, the pinned reference.  Adding the two ~700-ulp parts one after the other keeps the
+// roundings unbiased.  VELOCITY is insensitive to the form (its correction is >> 1 ulp).
 template <int N>
 __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
                                              const double (&j0)[N][3], double (&a1)[N][3],
@@ -241,10 +247,11 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
             pp[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[b][c], a0[b][c]), s.v[b][c]),
                                      s.p[b][c]);
             pv[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[b][c], a0[b][c]), s.v[b][c]);
-            c0[b][c] = __builtin_fma(k.kp_a, a0[b][c], k.kp_j0 * j0[b][c]);
-            d0[b][c] = __builtin_fma(k.kv_a, a0[b][c], k.kv_j0 * j0[b][c]);
             s.p[b][c] = pp[b][c];
             s.v[b][c] = pv[b][c];
+            c0[b][c] = k.kp_j0 * j0[b][c];                        // jerk part, start-of-step term
+            pp[b][c] = __builtin_fma(k.kp_a, a0[b][c], pp[b][c]); // pre_pos + c1*h^2*a0
+            d0[b][c] = __builtin_fma(k.kv_a, a0[b][c], k.kv_j0 * j0[b][c]);
         }
 #pragma unroll
     for (int round = 0; round < 2; round++) {
@@ -253,7 +260,7 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
         for (int b = 0; b < N; b++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                s.p[b][c] = pp[b][c] + __builtin_fma(-k.kp_a, a1[b][c], __builtin_fma(k.kp_j1, j1[b][c], c0[b][c]));
+                s.p[b][c] = __builtin_fma(-k.kp_a, a1[b][c], pp[b][c]) + __builtin_fma(k.kp_j1, j1[b][c], c0[b][c]);
                 s.v[b][c] = pv[b][c] + __builtin_fma(-k.kv_a, a1[b][c], __builtin_fma(k.kv_j1, j1[b][c], d0[b][c]));
             }
     }

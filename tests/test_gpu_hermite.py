@@ -146,3 +146,27 @@ def test_c2_headline_shape_properties(gpu, oracle):
     run_gpu(S, h, {"integrator": "hermite", "time_step": "0.0001"}, 0.05)
     h.vel *= -1
     assert rel_diff(h.pos[:, 1:], h0.pos[:, 1:]) < 1e-12 and rel_diff(h.vel[:, 1:], h0.vel[:, 1:]) < 1e-12
+
+
+def test_energy_error_distribution_matches_hermite_cpu_in_the_rounding_dominated_regime(gpu, oracle):
+    """py/tests/trivial.py BasicIntegration regime (r ~ 1, dt = 1e-4, 1e5 steps): truncation error is
+    ~1e-16, so |dE/E| is pure rounding behaviour.  hermite_cpu gives max 4e-14; the CUDA kernel's
+    factored corrector stagnates and gives 5.8e-13 (oracle "hermite" form).  The HIP kernel must
+    sit with hermite_cpu, the pinned reference (reference bar: < 1e-13, trivial.py:97-99)."""
+    S, O = gpu, oracle
+    rng = np.random.default_rng(14321)
+    e = O.generate(16, 3, planet_mass=1e-3)
+    for j in (1, 2):                                   # make_test_case: r = 1.4**(j-1), random phases
+        r = 1.4 ** (j - 1)
+        phi = rng.uniform(0, 2 * np.pi, 16)
+        e.pos[:, j] = np.stack([r * np.cos(phi), r * np.sin(phi), 0 * phi], -1)
+        e.vel[:, j] = np.stack([-np.sin(phi), np.cos(phi), 0 * phi], -1) / np.sqrt(r)
+    e0 = e.clone()
+    h = to_host(S, e)
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.0001"}, 10.0)
+    O.integrate(e, O.params("hermite_cpu", 10.0, time_step=1e-4), threads=8)
+    eo = O.energy_error(e, e0)
+    eg = np.abs((h.calc_total_energy() - O.total_energy(e0)) / O.total_energy(e0))
+    assert eo.max() < 1e-13
+    assert eg.max() < 1e-13 and eg.max() < 3 * eo.max() and np.median(eg) < 3 * np.median(eo)
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-12 and (h.time == e.time).all()
