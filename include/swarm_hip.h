@@ -59,7 +59,10 @@ enum swarm_hip_integrator {
 enum swarm_hip_monitor {
     SWARM_HIP_MON_EJECTION = 0,          /* monitors/stop_on_ejection.hpp */
     SWARM_HIP_MON_LOG_INTERVAL = 1,      /* monitors/log_time_interval.hpp (`*_log` names) */
-    SWARM_HIP_MON_EJECTION_OR_CLOSE = 2  /* monitors/composites.hpp:145-222 (`*_close_encounter`) */
+    SWARM_HIP_MON_EJECTION_OR_CLOSE = 2, /* monitors/composites.hpp:145-222 (`*_close_encounter`) */
+    SWARM_HIP_MON_MCE_STAT = 3           /* monitors/mercury_mce_stat.hpp: what plugins/hermite.cu:40 binds
+                                            to `hermite`; SWARM_HIP_HERMITE only, needs nbattr >= 3
+                                            (radius, rce, rphysics) and nsattr >= 1 */
 };
 
 typedef struct swarm_hip_ensemble {
@@ -102,12 +105,13 @@ typedef struct swarm_hip_launch {
     double rmax;                           /* rmax= (default FLT_MAX)                    */
     int32_t deactivate_on_ejection;        /* deactivate_on_ejection=                    */
     int32_t log_on_ejection;               /* log_on_ejection=                           */
-    int32_t verbose_on_ejection;           /* verbose_on_ejection= (no lprintf output)   */
+    int32_t verbose_on_ejection;           /* verbose_on_ejection= (lprintf records)     */
     int32_t deactivate_on_close_encounter; /* deactivate_on_close_encounter=             */
     int32_t log_on_close_encounter;        /* log_on_close_encounter=                    */
     int32_t verbose_on_close_encounter;    /* verbose_on_close_encounter=                */
     double close_approach;                 /* close_approach=                            */
     double log_interval;                   /* log_interval=                              */
+    double rceh;                           /* rceh= (mce_stat, default 1e-6)             */
     swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
     /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
     uint64_t *d_steps_accepted;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
-MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE = 0, 1, 2
+MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT = 0, 1, 2, 3
 INTEGRATORS = {
     "hermite_cpu": 0, "hermite": 1, "hermite_adap": 2, "rkck_fixed": 3, "rkck_adaptive": 4,
     "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9,
@@ -34,7 +34,8 @@ def build(force=False):
 
 class _Ens(C.Structure):
     _fields_ = [("nsys", C.c_int32), ("nbod", C.c_int32), ("pos", C.c_void_p), ("vel", C.c_void_p),
-                ("mass", C.c_void_p), ("time", C.c_void_p), ("state", C.c_void_p), ("id", C.c_void_p)]
+                ("mass", C.c_void_p), ("time", C.c_void_p), ("state", C.c_void_p), ("id", C.c_void_p),
+                ("nbattr", C.c_int32), ("nsattr", C.c_int32), ("battr", C.c_void_p), ("sattr", C.c_void_p)]
 
 
 class _Mon(C.Structure):
@@ -42,7 +43,8 @@ class _Mon(C.Structure):
                 ("log_on_ejection", C.c_int32), ("verbose_on_ejection", C.c_int32),
                 ("log_interval", C.c_double), ("close_approach", C.c_double),
                 ("deactivate_on_close_encounter", C.c_int32), ("log_on_close_encounter", C.c_int32),
-                ("verbose_on_close_encounter", C.c_int32)]
+                ("verbose_on_close_encounter", C.c_int32), ("rceh", C.c_double),
+                ("mce_time_step", C.c_double)]
 
 
 class _Log(C.Structure):
@@ -101,12 +103,14 @@ class Ensemble:
         return e
 
     def _c(self):
-        for k in ("pos", "vel", "mass", "time", "state", "id"):
+        for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
             a = getattr(self, k)
-            assert a.flags["C_CONTIGUOUS"], k
+            assert a.flags["C_CONTIGUOUS"] and a.dtype in (np.float64, np.int32), k
         return _Ens(self.nsys, self.nbod, self.pos.ctypes.data, self.vel.ctypes.data,
                     self.mass.ctypes.data, self.time.ctypes.data, self.state.ctypes.data,
-                    self.id.ctypes.data)
+                    self.id.ctypes.data, self.body_attr.shape[2], self.sys_attr.shape[1],
+                    self.body_attr.ctypes.data if self.body_attr.size else None,
+                    self.sys_attr.ctypes.data if self.sys_attr.size else None)
 
 
 def generate(nsys, nbod, spacing_factor=1.4, planet_mass=1e-4, ejection_factor=1.0 / np.sqrt(2),
@@ -122,10 +126,11 @@ def generate(nsys, nbod, spacing_factor=1.4, planet_mass=1e-4, ejection_factor=1
 
 def monitor(kind=MON_EJECTION, rmax=FLT_MAX, deactivate_on_ejection=0, log_on_ejection=0,
             verbose_on_ejection=0, log_interval=0.0, close_approach=0.0,
-            deactivate_on_close_encounter=0, log_on_close_encounter=0, verbose_on_close_encounter=0):
+            deactivate_on_close_encounter=0, log_on_close_encounter=0, verbose_on_close_encounter=0,
+            rceh=1e-6, mce_time_step=0.0):
     return _Mon(kind, rmax, deactivate_on_ejection, log_on_ejection, verbose_on_ejection,
                 log_interval, close_approach, deactivate_on_close_encounter, log_on_close_encounter,
-                verbose_on_close_encounter)
+                verbose_on_close_encounter, rceh, mce_time_step)
 
 
 def params(integrator, destination_time, max_iterations=10000000, time_step=0.0, time_step_factor=0.0,
@@ -162,9 +167,30 @@ def parse_log(raw):
             rec["bodies"] = bod[:, :7].copy()
             rec["body_id"] = np.frombuffer(raw, dtype=np.int32, count=16 * nb,
                                            offset=off + 32).reshape(nb, 16)[:, 14].copy()
+        elif msgid == -2:                      # MSG_PRINTF, gpulog_constants.h:35
+            rec["text"] = run_printf(raw[off:off + int(ln)])
         out.append(rec)
         off += int(ln)
     return out
+
+
+def run_printf(rec):
+    """lprintf.h:74-171 run_printf: format string at offset 8, arguments at natural alignment."""
+    import re
+    end = rec.index(b"\0", 8)
+    fmt = rec[8:end].decode()
+    at, args = end + 1, []
+    for m in re.finditer(r"%[^%cdiouxXeEfgGaAnps]*([%cdiouxXeEfgGaAnps])", fmt):
+        k = m.group(1)
+        if k in "cdiouxXp":
+            at = (at + 3) // 4 * 4
+            args.append(int(np.frombuffer(rec, dtype=np.int32, count=1, offset=at)[0]))
+            at += 4
+        elif k in "eEfgGaA":
+            at = (at + 7) // 8 * 8
+            args.append(float(np.frombuffer(rec, dtype=np.float64, count=1, offset=at)[0]))
+            at += 8
+    return fmt.replace("%lg", "%g") % tuple(args)
 
 
 def integrate(ens, par, mon=None, log=None, threads=1, max_attempts=1000000, counters=False,

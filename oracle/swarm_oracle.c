@@ -35,6 +35,9 @@ typedef struct {
     int32_t *state;
     int32_t *id;
     int number; /* array index of the system */
+    int nbattr, nsattr;
+    double *battr; /* [nbod][nbattr] or NULL */
+    double *sattr; /* [nsattr] or NULL */
 } sysref;
 
 static sysref sys_at(const orc_ensemble *e, int i) {
@@ -47,6 +50,10 @@ static sysref sys_at(const orc_ensemble *e, int i) {
     s.state = e->state + i;
     s.id = e->id + i;
     s.number = i;
+    s.nbattr = e->battr ? e->nbattr : 0;
+    s.nsattr = e->sattr ? e->nsattr : 0;
+    s.battr = e->battr ? e->battr + (size_t)i * e->nbod * e->nbattr : 0;
+    s.sattr = e->sattr ? e->sattr + (size_t)i * e->nsattr : 0;
     return s;
 }
 
@@ -100,10 +107,9 @@ int64_t orc_snapshot_record_size(int nbod) {
     return (len + 15) / 16 * 16;
 }
 
-static void log_system(orc_log *log, const sysref *s) {
-    if (!log || !log->buf) return;
-    int64_t len = orc_snapshot_record_size(s->nbod);
-    /* gpulog_write.h:14-22: reserve, roll back on overflow and drop the record */
+/* gpulog_write.h:14-22: reserve, roll back on overflow and drop the record */
+static uint8_t *log_reserve(orc_log *log, int64_t len) {
+    if (!log || !log->buf) return 0;
     uint8_t *r = 0;
 #ifdef _OPENMP
 #pragma omp critical(orc_log_cursor) /* gpulog_log.h:140-150 */
@@ -116,8 +122,47 @@ static void log_system(orc_log *log, const sysref *s) {
             log->len += len;
         }
     }
+    if (r) memset(r, 0, (size_t)len);
+    return r;
+}
+
+/* lprintf: log.write(MSG_PRINTF, fmt, args...), gpulog/bits/gpulog_printf.h, lprintf.h:47-58
+ * (floats widen to double), MSG_PRINTF = -2 (gpulog_constants.h:35).  Layout by pktsize<>
+ * (gpulog_msg_layout.h:112-204): header{msgid,len} | char fmt[N] at 8 (N counts the NUL) |
+ * every argument at its natural alignment | padded to 16.  types: 'i' int32, 'd' double.      */
+typedef struct {
+    char type;
+    int32_t i;
+    double d;
+} parg;
+static void log_printf(orc_log *log, const char *fmt, int nargs, const parg *a) {
+    int n = (int)strlen(fmt) + 1, at = 8 + n, off[10];
+    for (int k = 0; k < nargs; k++) {
+        int al = a[k].type == 'd' ? 8 : 4;
+        at = (at + al - 1) / al * al;
+        off[k] = at;
+        at += al;
+    }
+    int32_t len = (at + 15) / 16 * 16, msgid = -2;
+    uint8_t *r = log_reserve(log, len);
     if (!r) return;
-    memset(r, 0, (size_t)len);
+    memcpy(r, &msgid, 4);
+    memcpy(r + 4, &len, 4);
+    memcpy(r + 8, fmt, (size_t)n);
+    for (int k = 0; k < nargs; k++) {
+        if (a[k].type == 'd')
+            memcpy(r + off[k], &a[k].d, 8);
+        else
+            memcpy(r + off[k], &a[k].i, 4);
+    }
+}
+static parg PI_(int v) { parg p = {'i', v, 0}; return p; }
+static parg PD_(double v) { parg p = {'d', 0, v}; return p; }
+
+static void log_system(orc_log *log, const sysref *s) {
+    int64_t len = orc_snapshot_record_size(s->nbod);
+    uint8_t *r = log_reserve(log, len);
+    if (!r) return;
     int32_t msgid = 1 /* EVT_SNAPSHOT */, ilen = (int32_t)len, nbod = s->nbod;
     memcpy(r + 0, &msgid, 4);
     memcpy(r + 4, &ilen, 4);
@@ -143,6 +188,8 @@ typedef struct {
     orc_log *log;
     int ej_met, ce_met;   /* condition_met of each sub-monitor */
     double next_log_time; /* log_time_interval.hpp:118-119 */
+    /* mce_stat: CurrentSysStat shared data, mercury_mce_stat.hpp:57-73 */
+    double sh_pos[NB][3], sh_vel[NB][3], bb_sw[NB][3], bb_ne[NB][3];
 } monitor;
 
 static void mon_init(monitor *m, const orc_monitor *p, sysref *s, orc_log *log) {
@@ -165,8 +212,18 @@ static int ej_test_body(const monitor *m, int b) {
     if (rdotv <= 0.) return 0;
     double speed_sq = vx * vx + vy * vy + vz * vz;
     double epp = 0.5 * speed_sq * r / s->mass[b] - 1.;
-    if (fabs(epp) < 1e-4) return 1;
-    if (epp > 0) return 1;
+    if (fabs(epp) < 1e-4 || epp > 0) {
+        if (m->p->verbose_on_ejection) { /* L122-130 */
+            double energy = 0.5 * speed_sq - s->mass[b] / r;
+            parg a[6] = {PI_(s->number), PI_(b), PD_(*s->time), PD_(r), PD_(energy), PD_(epp)};
+            log_printf(m->log,
+                       fabs(epp) < 1e-4
+                           ? "Orbit is nearly parabolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n"
+                           : "Orbit is hyperbolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
+                       6, a);
+        }
+        return 1;
+    }
     return 0;
 }
 
@@ -194,7 +251,12 @@ static int ce_check(const monitor *m, int i, int j) {
     double a = 0.5 * (ri + ri); /* the reference uses body i twice (L130) */
     double rH3 = (s->mass[i] + s->mass[j]) / (3. * GM) * a * a * a;
     double dmin = m->p->close_approach;
-    return d * d * d < dmin * dmin * dmin * rH3;
+    int close_encounter = d * d * d < dmin * dmin * dmin * rH3;
+    if (close_encounter && m->p->verbose_on_close_encounter) { /* L137-141 */
+        parg a[5] = {PI_(s->number), PD_(*s->time), PI_(j), PI_(i), PD_(d)};
+        log_printf(m->log, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", 5, a);
+    }
+    return close_encounter;
 }
 
 /* stop_on_close_encounter::pass_one, stop_on_close_encounter.hpp:101-115 */
@@ -259,6 +321,205 @@ static void mon_call(monitor *m) {
     mon_pass_one(m);
     mon_pass_two(m);
     if (mon_need_to_log(m)) log_system(m->log, m->s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* mce_stat (Mercury close-encounter / collision statistics), monitors/mercury_mce_stat.hpp.
+ * Needs body attributes 0 (radius), 1 (rce), 2 (rphysics) and system attribute 0.  The
+ * reference's default build has NUM_PLANET_ATTRIBUTES=1, where attribute(1),(2) index past the
+ * Body struct: defined behaviour exists only for nbattr >= 3, which is what
+ * is restated.  PARITY UNPINNED: no fixture, no CPU twin and no CUDA build of it exists.      */
+#define MCE_PI 3.14159265358979      /* L26 */
+#define MCE_THIRD 0.3333333333333333 /* L27 */
+#define BATTR(s, b, k) ((s)->battr[(size_t)(b) * (s)->nbattr + (k)])
+
+/* init(thread_in_system), L134-166.  `0 < t < nbod` is always true, so thread 0 runs the first
+ * block too and then overwrites its result with 0; threads >= nbod index out of bounds in the
+ * reference and are not restated. */
+static void mce_init(sysref *s, const orc_monitor *p) {
+    for (int t = 1; t < s->nbod; t++) {
+        double gm = s->mass[0] + s->mass[t];
+        double r = sqrt(s->pos[t][0] * s->pos[t][0] + s->pos[t][1] * s->pos[t][1] +
+                        s->pos[t][2] * s->pos[t][2]);
+        double vi_max = s->vel[t][0] * s->vel[t][0] + s->vel[t][1] * s->vel[t][1] +
+                        s->vel[t][2] * s->vel[t][2];
+        double a = gm * r / (2 * gm - r * vi_max);
+        if (a <= 0) a = r;
+        double hill = a * pow(MCE_THIRD * s->mass[t] / s->mass[0], MCE_THIRD);
+        double rad = BATTR(s, t, 0);
+        double rho = s->mass[t] / (4 * MCE_THIRD * MCE_PI * rad * rad * rad);
+        BATTR(s, t, 1) = hill * p->rceh;
+        BATTR(s, t, 2) = hill / a * pow(2.25 * s->mass[0] / (MCE_PI * rho), MCE_THIRD);
+    }
+    BATTR(s, 0, 1) = 0.0;
+    BATTR(s, 0, 2) = 0.0;
+}
+
+/* pass_one(b,c), L192-219: bounding box of each planet's path over the step */
+static void mce_pass_one(monitor *m) {
+    sysref *s = m->s;
+    const double timestep = m->p->mce_time_step;
+    for (int b = 1; b < s->nbod; b++)
+        for (int c = 0; c < 3; c++) {
+            double sp = m->sh_pos[b][c], sv = m->sh_vel[b][c], gp = s->pos[b][c], gv = s->vel[b][c];
+            m->bb_sw[b][c] = fmin(sp, gp);
+            m->bb_ne[b][c] = fmax(sp, gp);
+            if ((sv < 0 && gv > 0) || (sv > 0 && gv < 0)) {
+                double temp = sv * gp - gv * sp - 0.5 * timestep * sv * gv / (sv - gv);
+                m->bb_sw[b][c] = fmin(m->bb_sw[b][c], temp);
+                m->bb_ne[b][c] = fmax(m->bb_ne[b][c], temp);
+            }
+            double tmp = BATTR(s, b, 1) * 1.2;
+            m->bb_sw[b][c] -= tmp;
+            m->bb_ne[b][c] += tmp;
+        }
+}
+
+/* pass_two(thread 0), L222-433.  Mixed float/double arithmetic as written there. */
+static void mce_pass_two(monitor *m) {
+    sysref *s = m->s;
+    const int nbod = s->nbod;
+    const double timestep = m->p->mce_time_step;
+    double(*sp)[3] = m->sh_pos, (*sv)[3] = m->sh_vel;
+    int i, j;
+    /* planet - planet */
+    for (j = 2; j < nbod; j++)
+        for (i = 1; i < j; i++) {
+            if (m->bb_ne[i][0] >= m->bb_sw[j][0] && m->bb_ne[j][0] >= m->bb_sw[i][0])
+                if (m->bb_ne[i][1] >= m->bb_sw[j][1] && m->bb_ne[j][1] >= m->bb_sw[i][1])
+                    if (m->bb_ne[i][2] >= m->bb_sw[j][2] && m->bb_ne[j][2] >= m->bb_sw[i][2]) {
+                        if (s->mass[i] > 0 && s->mass[j] > 0) {
+                            double dx0 = sp[i][0] - sp[j][0], dy0 = sp[i][1] - sp[j][1], dz0 = sp[i][2] - sp[j][2];
+                            double du0 = sv[i][0] - sv[j][0], dv0 = sv[i][1] - sv[j][1], dw0 = sv[i][2] - sv[j][2];
+                            double d0t = (dx0 * du0 + dy0 * dv0 + dz0 * dw0) * 2.0;
+                            double dx1 = s->pos[i][0] - s->pos[j][0], dy1 = s->pos[i][1] - s->pos[j][1],
+                                   dz1 = s->pos[i][2] - s->pos[j][2];
+                            double du1 = s->vel[i][0] - s->vel[j][0], dv1 = s->vel[i][1] - s->vel[j][1],
+                                   dw1 = s->vel[i][2] - s->vel[j][2];
+                            double d1t = (dx1 * du1 + dy1 * dv1 + dz1 * dw1) * 2.0;
+                            double d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                            double d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                            double d2min, tmin, tau;
+                            if (d0t > 0 && d1t < 0) {
+                                if (d0 < d1) {
+                                    d2min = d0;
+                                    tmin = -timestep;
+                                } else {
+                                    d2min = d1;
+                                    tmin = 0.0;
+                                }
+                            } else { /* Hermite interpolation of the separation, float coefficients */
+                                float tmp = 6.0 * (d0 - d1);
+                                float a = tmp + 3.0 * timestep * (d0t + d1t);
+                                float b = tmp + 2.0 * timestep * (d0t + 2.0 * d1t);
+                                float c = timestep * d1t;
+                                tmp = -0.5 * (b + ((b > 0) ? 1.0 : (-1.0)) * sqrt(fmax((double)(b * b - 4 * a * c), 0.0)));
+                                if (tmp == 0.0)
+                                    tau = 0.0;
+                                else
+                                    tau = c / tmp;
+                                tau = fmin(tau, 0.0);
+                                tau = fmax(tau, -1.0);
+                                tmin = tau * timestep;
+                                tmp = 1.0 + tau;
+                                d2min = tau * tau * ((3.0 + 2.0 * tau) * d0 + tmp * timestep * d0t) +
+                                        tmp * tmp * ((1.0 - 2.0 * tau) * d1 + tau * timestep * d1t);
+                                d2min = fmax(d2min, 0.0);
+                            }
+                            float d2hit = fmax(BATTR(s, i, 2), BATTR(s, j, 2));
+                            d2hit = d2hit * d2hit;
+                            if (d2min <= d2hit) {
+                                if (s->mass[i] < s->mass[j]) { /* L312: swaps the LOOP variables */
+                                    int k = i;
+                                    i = j;
+                                    j = k;
+                                }
+                                parg a[4] = {PI_(*s->id), PI_(i), PI_(j), PD_(*s->time + tmin)};
+                                log_printf(m->log, "Hitting detected: sysid = %d, i = %d, j = %d, time= %f\n", 4, a);
+                                float msum = s->mass[i] + s->mass[j];
+                                float mredu = s->mass[i] * s->mass[j] / msum;
+                                if (s->sattr) /* energy lost */
+                                    s->sattr[0] = 0.5 * mredu * (du1 * du1 + dv1 * dv1 + dw1 * dw1) -
+                                                  s->mass[i] * s->mass[j] / sqrt(dx1 * dx1 + dy1 * dy1 + dz1 * dz1);
+                                float tmp1 = s->mass[i] / msum;
+                                float tmp2 = s->mass[j] / msum;
+                                for (int c = 0; c < 3; c++) {
+                                    s->pos[i][c] = s->pos[i][c] * tmp1 + s->pos[j][c] * tmp2;
+                                    s->vel[i][c] = s->vel[i][c] * tmp1 + s->vel[j][c] * tmp2;
+                                }
+                                s->mass[i] = msum;
+                                for (int c = 0; c < 3; c++) {
+                                    s->pos[j][c] *= 100;
+                                    s->vel[j][c] = 0.0;
+                                }
+                                s->mass[j] = 0.0;
+                            }
+                        } else {
+                            parg a[1] = {PD_(*s->time)};
+                            log_printf(m->log, "3 planets in collision: System halted ! T=%f\n", 1, a);
+                            log_system(m->log, s);
+                            *s->state = ORC_DISABLED;
+                        }
+                    }
+        }
+    /* sun - planet */
+    i = 0;
+    for (j = 1; j < nbod; j++) {
+        float rr0 = sp[j][0] * sp[j][0] + sp[j][1] * sp[j][1] + sp[j][2] * sp[j][2];
+        float rr1 = s->pos[j][0] * s->pos[j][0] + s->pos[j][1] * s->pos[j][1] + s->pos[j][2] * s->pos[j][2];
+        float rv0 = sv[j][0] * sp[j][0] + sv[j][1] * sp[j][1] + sv[j][2] * sp[j][2];
+        /* L361: the z term is pos*pos in the reference */
+        float rv1 = s->vel[j][0] * s->pos[j][0] + s->vel[j][1] * s->pos[j][1] + s->pos[j][2] * s->pos[j][2];
+        if ((rv0 * timestep <= -1e-6 && rv1 * timestep >= 1e-6) ||
+            (fminf(rr0, rr1) <= BATTR(s, 0, 0) * BATTR(s, 0, 0))) {
+            if (s->mass[j] > 0) {
+                float hx = sp[j][1] * sv[j][2] - sp[j][2] * sv[j][1];
+                float hy = sp[j][2] * sv[j][0] - sp[j][0] * sv[j][2];
+                float hz = sp[j][0] * sv[j][1] - sp[j][1] * sv[j][0];
+                float v2 = sv[j][0] * sv[j][0] + sv[j][1] * sv[j][1] + sv[j][2] * sv[j][2];
+                float h2 = hx * hx + hy * hy + hz * hz;
+                float pp = h2 / (s->mass[i] + s->mass[j]);
+                float r0 = sqrtf(rr0);
+                float temp = 1.0 + pp * (v2 / (s->mass[i] + s->mass[j]) - 2.0 / r0);
+                float e = sqrt(fmax((double)temp, 0.0));
+                float q = pp / (1.0 + e);
+                if (q <= BATTR(s, i, 0)) {
+                    parg a[3] = {PI_(*s->id), PD_(*s->time), PI_(j)};
+                    log_printf(m->log, "Hitting with the sun detected: sysid = %d, time = %f, j=%d\n", 3, a);
+                    float tmp2 = s->mass[j] / (s->mass[j] + s->mass[i]);
+                    for (int c = 0; c < 3; c++) {
+                        s->pos[i][c] = tmp2 * s->pos[j][c];
+                        s->vel[i][c] = tmp2 * s->vel[j][c];
+                    }
+                    s->mass[i] = s->mass[j] + s->mass[i];
+                    for (int c = 0; c < 3; c++) {
+                        s->pos[j][c] *= 100.0;
+                        s->vel[j][c] *= 0.0;
+                    }
+                    s->mass[j] = 0.0;
+                    for (int k = 1; k < nbod; k++)
+                        if (k != j)
+                            for (int c = 0; c < 3; c++) {
+                                s->pos[k][c] = s->pos[k][c] - s->pos[0][c];
+                                s->vel[k][c] = s->vel[k][c] - s->vel[0][c];
+                            }
+                }
+            } else {
+                log_printf(m->log, "2 planets and the sun in collision: System halted !\n", 0, 0);
+                log_system(m->log, s);
+                *s->state = ORC_DISABLED;
+            }
+        }
+    }
+}
+
+/* operator()(thread, b, c, pos, vel), L168-186: (pos, vel) = state at the START of the step */
+static void mce_call(monitor *m, double c_pos[][3], double c_vel[][3]) {
+    memcpy(m->sh_pos, c_pos, sizeof(double) * 3 * m->s->nbod);
+    memcpy(m->sh_vel, c_vel, sizeof(double) * 3 * m->s->nbod);
+    mce_pass_one(m);
+    mce_pass_two(m);
+    /* need_to_log_system() is constant false (L124-130) */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -423,9 +684,11 @@ static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor 
                                int adaptive, int64_t *accepted) {
     const int nbod = s.nbod;
     double pos[NB][3], vel[NB][3], acc0[NB][3], jerk0[NB][3], acc1[NB][3], jerk1[NB][3];
-    double pre_pos[NB][3], pre_vel[NB][3];
+    double pre_pos[NB][3], pre_vel[NB][3], c_pos[NB][3], c_vel[NB][3];
+    const int mce = (M->kind == ORC_MON_MCE_STAT);
     monitor mon;
     mon_init(&mon, M, &s, log);
+    if (mce) mce_init(&s, M); /* hermite_integrator.hpp:99 */
     memcpy(pos, s.pos, sizeof(double) * 3 * nbod);
     memcpy(vel, s.vel, sizeof(double) * 3 * nbod);
     if (adaptive) mon_call(&mon); /* hermite_adap.hpp:130: monitor runs once before the loop */
@@ -445,10 +708,15 @@ static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor 
         } else
             h = P->time_step;
         if (*s.time + h > P->destination_time) h = P->destination_time - *s.time;
+        /* L124-132: the predictor starts from the GLOBAL pos/vel (c_pos, c_vel) but the position
+         * predictor uses the register `vel`; they differ only after a monitor rewrote the system
+         * (mce_stat merges), when acc0/jerk0 are stale as well. */
+        memcpy(c_pos, s.pos, sizeof(double) * 3 * nbod);
+        memcpy(c_vel, s.vel, sizeof(double) * 3 * nbod);
         for (int b = 0; b < nbod; b++)
             for (int c = 0; c < 3; c++) {
-                pos[b][c] = pos[b][c] + h * (vel[b][c] + (h * 0.5) * (acc0[b][c] + (h / 3.0) * jerk0[b][c]));
-                vel[b][c] = vel[b][c] + h * (acc0[b][c] + (h * 0.5) * jerk0[b][c]);
+                pos[b][c] = c_pos[b][c] + h * (vel[b][c] + (h * 0.5) * (acc0[b][c] + (h / 3.0) * jerk0[b][c]));
+                vel[b][c] = c_vel[b][c] + h * (acc0[b][c] + (h * 0.5) * jerk0[b][c]);
                 pre_pos[b][c] = pos[b][c], pre_vel[b][c] = vel[b][c];
             }
         for (int round = 0; round < 2; round++) {
@@ -471,7 +739,10 @@ static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor 
         memcpy(s.vel, vel, sizeof(double) * 3 * nbod);
         *s.time += h;
         if (accepted) (*accepted)++;
-        mon_call(&mon);
+        if (mce)
+            mce_call(&mon, c_pos, c_vel); /* L173 */
+        else
+            mon_call(&mon);
         if (*s.state == ORC_ACTIVE) {
             if (adaptive ? (*s.time >= P->destination_time)
                          : (*s.time > P->destination_time - 1e-12))
@@ -949,6 +1220,8 @@ int orc_max_threads(void) {
 int orc_launch(const orc_ensemble *e, const orc_params *p, const orc_monitor *m, orc_log *log,
                const orc_counters *cnt, int threads) {
     if (e->nbod < 3 || e->nbod > NB) return -1;
+    if (m->kind == ORC_MON_MCE_STAT &&
+        (p->integrator != ORC_INT_HERMITE || !e->battr || e->nbattr < 3)) return -2;
     (void)threads;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)

@@ -30,10 +30,15 @@ typedef struct {
     int32_t nsys, nbod;
     double *pos, *vel, *mass, *time;
     int32_t *state, *id;
+    /* attributes (ensemble.hpp:131-150,227-238): battr[nsys][nbod][nbattr], sattr[nsys][nsattr];
+     * may be NULL with nbattr/nsattr 0 for integrators/monitors that never touch them */
+    int32_t nbattr, nsattr;
+    double *battr, *sattr;
 } orc_ensemble;
 
 /* monitor kinds: which reference monitor class the plugin name binds (src/plugins/ *.cu) */
-enum { ORC_MON_EJECTION = 0, ORC_MON_LOG_INTERVAL = 1, ORC_MON_EJECTION_OR_CLOSE = 2 };
+enum { ORC_MON_EJECTION = 0, ORC_MON_LOG_INTERVAL = 1, ORC_MON_EJECTION_OR_CLOSE = 2,
+       ORC_MON_MCE_STAT = 3 /* monitors/mercury_mce_stat.hpp, bound to `hermite` (plugins/hermite.cu:40) */ };
 
 typedef struct {
     int32_t kind;
@@ -45,6 +50,9 @@ typedef struct {
     /* stop_on_close_encounter_param, src/monitors/stop_on_close_encounter.hpp */
     double close_approach;
     int32_t deactivate_on_close_encounter, log_on_close_encounter, verbose_on_close_encounter;
+    /* mce_stat_params, src/monitors/mercury_mce_stat.hpp:36-55 (dmin = close_approach, unused) */
+    double rceh;          /* rceh= (default 1e-6) */
+    double mce_time_step; /* time_step= */
 } orc_monitor;
 
 /* append-only record buffer: the host twin of gpulog::log_base (bits/gpulog_log.h:171-178) */

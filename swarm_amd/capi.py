@@ -10,7 +10,7 @@ CHUNK = 64
 MIN_NBOD, MAX_NBOD = 3, 8
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP = range(1, 10)
-MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE = 0, 1, 2
+MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT = 0, 1, 2, 3
 
 
 class SwarmHipError(RuntimeError):
@@ -35,7 +35,8 @@ class LaunchStruct(C.Structure):
                 ("deactivate_on_ejection", C.c_int32), ("log_on_ejection", C.c_int32),
                 ("verbose_on_ejection", C.c_int32), ("deactivate_on_close_encounter", C.c_int32),
                 ("log_on_close_encounter", C.c_int32), ("verbose_on_close_encounter", C.c_int32),
-                ("close_approach", C.c_double), ("log_interval", C.c_double), ("log", LogStruct),
+                ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double),
+                ("log", LogStruct),
                 ("d_steps_accepted", C.c_void_p), ("d_steps_attempted", C.c_void_p),
                 ("stream", C.c_void_p)]
 

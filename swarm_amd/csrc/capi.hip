@@ -298,7 +298,7 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     c.ip.error_tolerance = a->error_tolerance;
     c.ip.max_timestep = a->max_timestep;
     c.ip.timestep_scale = a->timestep_scale;
-    if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_EJECTION_OR_CLOSE) {
+    if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_MCE_STAT) {
         set_error("unknown monitor id %d", a->monitor);
         return SWARM_HIP_EINVAL;
     }
@@ -314,6 +314,11 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     c.mp.r2_below = (a->rmax > 0 && a->rmax < 1e150) ? a->rmax * a->rmax * (1.0 - 8 * DBL_EPSILON) : 0.0;
     c.mp.dmin3 = a->close_approach * a->close_approach * a->close_approach;
     c.mp.log_interval = a->log_interval;
+    c.mp.ej_verbose = a->verbose_on_ejection != 0;
+    c.mp.ce_verbose = a->verbose_on_close_encounter != 0;
+    c.mp.dmin = a->close_approach;
+    c.mp.rceh = a->rceh;
+    c.mp.mce_time_step = a->time_step; // mce_stat_params reads the same time_step= key (L45)
     c.lg.buf = a->log.d_buf;
     c.lg.cursor = a->log.d_cursor;
     c.lg.cap = a->log.capacity;
@@ -358,8 +363,13 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     default:
         break;
     }
+    if (a->monitor == SWARM_HIP_MON_MCE_STAT && a->integrator != SWARM_HIP_HERMITE) {
+        set_error("monitor mce_stat is bound to integrator hermite only (plugins/hermite.cu:40)");
+        return SWARM_HIP_EINVAL;
+    }
     switch (a->integrator) {
     case SWARM_HIP_HERMITE:
+        if (a->monitor == SWARM_HIP_MON_MCE_STAT) return launch_hermite_mce(c);
         return launch_hermite(c, false);
     case SWARM_HIP_HERMITE_ADAP:
         return launch_hermite(c, true);

@@ -32,6 +32,9 @@ struct MonParams {
     double r2_below; // r2 < r2_below  =>  sqrt(r2) < rmax for certain (host-computed lower bound)
     double dmin3;    // close_approach^3
     double log_interval;
+    int ej_verbose, ce_verbose; // verbose_on_*: lprintf records (gpulog MSG_PRINTF)
+    double dmin;                // close_approach
+    double rceh, mce_time_step; // mce_stat_params (monitors/mercury_mce_stat.hpp:36-55)
 };
 
 struct LogBuf {
@@ -58,6 +61,7 @@ struct State {
     double p[N][3], v[N][3], m[N];
     double t;
     int state, id;
+    int number; // index of the system in the ensemble (SystemRef::number())
 };
 
 template <int N>
@@ -77,6 +81,7 @@ __device__ __forceinline__ void load_state(const EnsView &e, int gid, State<N> &
     s.t = e.sysd[(size_t)chunk * e.nsf * W + lane];
     s.state = e.sysi[(size_t)chunk * 2 * W + lane];
     s.id = e.sysi[(size_t)chunk * 2 * W + W + lane];
+    s.number = gid;
 }
 
 template <int N>
@@ -235,16 +240,19 @@ struct StepConsts {
 // drifts 6.6e-12 in position and conserves energy 10x worse (5.8e-13 vs 4.1e-14) than
 // hermite_cpu, the pinned reference.  Adding the two ~700-ulp parts one after the other keeps the
 // roundings unbiased.  VELOCITY is insensitive to the form (its correction is >> 1 ulp).
+// `vp` = the velocity the POSITION predictor uses: the reference kernel predicts from the global
+// pos/vel but with its register copy of vel (hermite_integrator.hpp:124-132); the two differ only
+// after a monitor rewrote the system (mce_stat merges).
 template <int N>
 __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
                                              const double (&j0)[N][3], double (&a1)[N][3],
-                                             double (&j1)[N][3]) {
+                                             double (&j1)[N][3], const double (&vp)[N][3]) {
     double pp[N][3], pv[N][3], c0[N][3], d0[N][3];
 #pragma unroll
     for (int b = 0; b < N; b++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            pp[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[b][c], a0[b][c]), s.v[b][c]),
+            pp[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[b][c], a0[b][c]), vp[b][c]),
                                      s.p[b][c]);
             pv[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[b][c], a0[b][c]), s.v[b][c]);
             s.p[b][c] = pp[b][c];
@@ -266,12 +274,49 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
     }
 }
 
+template <int N>
+__device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
+                                             const double (&j0)[N][3], double (&a1)[N][3],
+                                             double (&j1)[N][3]) {
+    double vp[N][3];
+#pragma unroll
+    for (int b = 0; b < N; b++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) vp[b][c] = s.v[b][c];
+    hermite_step<N>(s, k, a0, j0, a1, j1, vp);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device event buffer.  Record bytes = reference EVT_SNAPSHOT (swarm/log/log.hpp:313-326,
 // log/types.hpp:37-56, gpulog/bits/gpulog_msg_layout.h:112-204).  The reference reserves with
 // one atomicAdd per record on a single int (bits/gpulog_write.h:14-22); here the lanes of a
 // wavefront that log in the same step reserve together: one atomic per wavefront.
 __device__ __forceinline__ int snapshot_len(int nbod) { return (32 + 64 * nbod + 15) / 16 * 16; }
+
+template <int N>
+__device__ __forceinline__ void snapshot_fill(uint8_t *r, double t, int id, int state, const double (&p)[N][3],
+                                              const double (&v)[N][3], const double (&m)[N]) {
+    const int len = snapshot_len(N);
+    int32_t *ri = reinterpret_cast<int32_t *>(r);
+    double *rd = reinterpret_cast<double *>(r);
+    ri[0] = 1; // EVT_SNAPSHOT
+    ri[1] = len;
+    rd[1] = t;
+    ri[4] = id;
+    ri[5] = state;
+    ri[6] = N;
+    ri[7] = 0;
+#pragma unroll
+    for (int b = 0; b < N; b++) {
+        double *q = rd + 4 + 8 * b;
+        q[0] = p[b][0], q[1] = p[b][1], q[2] = p[b][2];
+        q[3] = v[b][0], q[4] = v[b][1], q[5] = v[b][2];
+        q[6] = m[b];
+        reinterpret_cast<int32_t *>(q + 7)[0] = b;
+        reinterpret_cast<int32_t *>(q + 7)[1] = 0;
+    }
+    for (int k = (32 + 64 * N) / 8; k < len / 8; k++) rd[k] = 0.0; // pad to 16
+}
 
 template <int N>
 __device__ __forceinline__ void log_system(const LogBuf &lg, const State<N> &s, bool want) {
@@ -293,27 +338,66 @@ __device__ __forceinline__ void log_system(const LogBuf &lg, const State<N> &s, 
         if (lg.cursor) atomicAdd(lg.cursor + 1, 1);
         return;
     }
-    uint8_t *r = lg.buf + off;
-    int32_t *ri = reinterpret_cast<int32_t *>(r);
-    double *rd = reinterpret_cast<double *>(r);
-    ri[0] = 1; // EVT_SNAPSHOT
-    ri[1] = len;
-    rd[1] = s.t;
-    ri[4] = s.id;
-    ri[5] = s.state;
-    ri[6] = N;
-    ri[7] = 0;
-#pragma unroll
-    for (int b = 0; b < N; b++) {
-        double *q = rd + 4 + 8 * b;
-        q[0] = s.p[b][0], q[1] = s.p[b][1], q[2] = s.p[b][2];
-        q[3] = s.v[b][0], q[4] = s.v[b][1], q[5] = s.v[b][2];
-        q[6] = s.m[b];
-        reinterpret_cast<int32_t *>(q + 7)[0] = b;
-        reinterpret_cast<int32_t *>(q + 7)[1] = 0;
-    }
-    for (int k = (32 + 64 * N) / 8; k < len / 8; k++) rd[k] = 0.0; // pad to 16
+    snapshot_fill<N>(lg.buf + off, s.t, s.id, s.state, s.p, s.v, s.m);
 }
+
+// Per-lane reservation (bits/gpulog_write.h:14-22) for the rare records written from divergent
+// code: lprintf lines and the snapshots mce_stat writes in the middle of its pass.
+__device__ __forceinline__ uint8_t *log_reserve_lane(const LogBuf &lg, int len) {
+    if (!lg.buf) {
+        if (lg.cursor) atomicAdd(lg.cursor + 1, 1);
+        return nullptr;
+    }
+    const int off = atomicAdd(lg.cursor, len);
+    if ((long long)off + len > (long long)lg.cap) {
+        atomicSub(lg.cursor, len);
+        atomicAdd(lg.cursor + 1, 1);
+        return nullptr;
+    }
+    return lg.buf + off;
+}
+
+// lprintf = log.write(MSG_PRINTF, fmt, args...) (gpulog/bits/gpulog_printf.h, lprintf.h:47-58).
+// Record: header{msgid=-2 (gpulog_constants.h:35), len} | char fmt[n] at 8, NUL included | each
+// argument at its natural alignment (int32: 4, double: 8) | padded to 16
+// (bits/gpulog_msg_layout.h:112-204).  The host replays them with run_printf (lprintf.h:74-171).
+struct PArg {
+    int is_double;
+    int i;
+    double d;
+};
+__device__ __forceinline__ PArg parg(int v) { return PArg{0, v, 0.0}; }
+__device__ __forceinline__ PArg parg(double v) { return PArg{1, 0, v}; }
+
+static __device__ __noinline__ void log_printf_lane(const LogBuf &lg, const char *fmt, int n, const PArg *a, int nargs) {
+    int at = 8 + n;
+    for (int k = 0; k < nargs; k++) {
+        const int al = a[k].is_double ? 8 : 4;
+        at = (at + al - 1) / al * al + al;
+    }
+    const int len = (at + 15) / 16 * 16;
+    uint8_t *r = log_reserve_lane(lg, len);
+    if (!r) return;
+    for (int k = 8; k < len; k += 4) *reinterpret_cast<int32_t *>(r + k) = 0;
+    reinterpret_cast<int32_t *>(r)[0] = -2; // MSG_PRINTF
+    reinterpret_cast<int32_t *>(r)[1] = len;
+    for (int k = 0; k < n; k++) r[8 + k] = (uint8_t)fmt[k];
+    at = 8 + n;
+    for (int k = 0; k < nargs; k++) {
+        const int al = a[k].is_double ? 8 : 4;
+        at = (at + al - 1) / al * al;
+        if (a[k].is_double)
+            *reinterpret_cast<double *>(r + at) = a[k].d;
+        else
+            *reinterpret_cast<int32_t *>(r + at) = a[k].i;
+        at += al;
+    }
+}
+#define SWH_LPRINTF(lg, fmt, ...)                                  \
+    do {                                                           \
+        const PArg _a[] = {__VA_ARGS__};                           \
+        log_printf_lane(lg, fmt, (int)sizeof(fmt), _a, (int)(sizeof(_a) / sizeof(_a[0]))); \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // Monitors.  Every comparison that decides an integer outcome is evaluated without FMA
@@ -332,7 +416,7 @@ __device__ __forceinline__ void mon_init(MonState &ms, const State<N> &s) {
 
 // stop_on_ejection::test_body, monitors/stop_on_ejection.hpp:108-138
 template <int N>
-__device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const MonParams &mp) {
+__device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const MonParams &mp, const LogBuf &lg) {
 #pragma clang fp contract(off)
     const double x = s.p[b][0], y = s.p[b][1], z = s.p[b][2];
     const double r2 = x * x + y * y + z * z;
@@ -344,14 +428,25 @@ __device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const Mon
     if (rdotv <= 0.) return false;
     const double speed_sq = vx * vx + vy * vy + vz * vz;
     const double epp = 0.5 * speed_sq * r / s.m[b] - 1.;
-    if (fabs(epp) < 1e-4) return true;
-    if (epp > 0) return true;
+    const bool parabolic = fabs(epp) < 1e-4;
+    if (parabolic || epp > 0) {
+        if (mp.ej_verbose) { // L122-130
+            const double energy = 0.5 * speed_sq - s.m[b] / r;
+            if (parabolic)
+                SWH_LPRINTF(lg, "Orbit is nearly parabolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
+                            parg(s.number), parg(b), parg(s.t), parg(r), parg(energy), parg(epp));
+            else
+                SWH_LPRINTF(lg, "Orbit is hyperbolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
+                            parg(s.number), parg(b), parg(s.t), parg(r), parg(energy), parg(epp));
+        }
+        return true;
+    }
     return false;
 }
 
 // stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142
 template <int N>
-__device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp) {
+__device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp, const LogBuf &lg) {
 #pragma clang fp contract(off)
     const double dx = s.p[i][0] - s.p[j][0], dy = s.p[i][1] - s.p[j][1], dz = s.p[i][2] - s.p[j][2];
     const double d = sqrt(dx * dx + dy * dy + dz * dz);
@@ -359,14 +454,19 @@ __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const 
     const double ri = sqrt(s.p[i][0] * s.p[i][0] + s.p[i][1] * s.p[i][1] + s.p[i][2] * s.p[i][2]);
     const double a = 0.5 * (ri + ri); // the reference uses body i twice (L130)
     const double rH3 = (s.m[i] + s.m[j]) / (3. * GM) * a * a * a;
-    return d * d * d < mp.dmin3 * rH3;
+    const bool close_encounter = d * d * d < mp.dmin3 * rH3;
+    if (close_encounter && mp.ce_verbose) // L137-141
+        SWH_LPRINTF(lg, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", parg(s.number), parg(s.t),
+                    parg(j), parg(i), parg(d));
+    return close_encounter;
 }
 
 // pass_one of the bound monitor (stop_on_ejection.hpp:177-193, log_time_interval.hpp:98-111,
 // stop_on_close_encounter.hpp:101-115, composites.hpp:199-200).  Returns need_full_test
 // ("this system needs standard coordinates").
 template <int N>
-__device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, const MonParams &mp) {
+__device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, const MonParams &mp,
+                                             const LogBuf &lg) {
     bool need_full = false;
     if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
         ms.ej_met = false;
@@ -381,7 +481,7 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
     ms.ej_met = false;
     if (mp.ej_any) {
 #pragma unroll
-        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body(s, b, mp);
+        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body(s, b, mp, lg);
         if (ms.ej_met && mp.ej_log) need_full = true;
     }
     if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && !need_full) { // short-circuit ||
@@ -390,7 +490,7 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
 #pragma unroll
             for (int b = 2; b < N; b++)
 #pragma unroll
-                for (int d = 1; d < b; d++) ms.ce_met = ms.ce_met || ce_check(s, b, d, mp);
+                for (int d = 1; d < b; d++) ms.ce_met = ms.ce_met || ce_check(s, b, d, mp, lg);
             if (ms.ce_met && mp.ce_log) need_full = true;
         }
     }
@@ -421,7 +521,7 @@ __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonPar
                                          const LogBuf &lg, bool participate) {
     bool want = false;
     if (participate) {
-        mon_pass_one(ms, s, mp);
+        mon_pass_one(ms, s, mp, lg);
         mon_pass_two(ms, s, mp);
         want = mon_need_log(ms, mp);
     }

@@ -14,7 +14,10 @@ namespace swarm {
 
 class ensemble {
 public:
-    static const int NUM_BODY_ATTRIBUTES = 1; // src/config.h.in NUM_PLANET_ATTRIBUTES default
+#ifndef SWARM_NUM_PLANET_ATTRIBUTES
+#define SWARM_NUM_PLANET_ATTRIBUTES 1 // src/config.h.in NUM_PLANET_ATTRIBUTES, cmake/variables.cmake:47 default
+#endif
+    static const int NUM_BODY_ATTRIBUTES = SWARM_NUM_PLANET_ATTRIBUTES;
     static const int NUM_SYS_ATTRIBUTES = 1;
     // ensemble.hpp:269-274
     enum { SYSTEM_ACTIVE = 0, SYSTEM_INACTIVE = 1, SYSTEM_NEEDS_EXAM = 2, SYSTEM_DISABLED = -1 };

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <iostream>
 #include <memory>
 #include <string>
 #include <vector>
@@ -48,6 +49,10 @@ public:
     virtual ~binary_writer();
     virtual void process(const char *p, size_t n);
 };
+
+// lprintf host side, swarm/log/gpulog/lprintf.h:74-195
+std::string run_printf(const char *record);
+int replay_printf(std::ostream &out, const char *buffer, size_t bytes);
 
 // log::manager, logmanager.hpp / logmanager.cpp:37-87
 class manager {

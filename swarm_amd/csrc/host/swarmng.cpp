@@ -107,6 +107,68 @@ Pmanager &manager::default_log() {
     }
     return lm;
 }
+// run_printf / replay_printf, swarm/log/gpulog/lprintf.h:74-195: format every MSG_PRINTF record
+// (header | char fmt[N] at 8 | arguments at natural alignment) and write it to `out`.
+std::string run_printf(const char *rec) {
+    int32_t msgid;
+    std::memcpy(&msgid, rec, 4);
+    if (msgid != -2 /* gpulog::MSG_PRINTF, bits/gpulog_constants.h:35 */) return "";
+    std::string fmt(rec + 8);
+    size_t at = 8 + fmt.size() + 1;
+    std::string out;
+    char buf[1024];
+    size_t pos = 0;
+    while (pos < fmt.size()) {
+        size_t pc = fmt.find('%', pos);
+        if (pc == std::string::npos) break;
+        out.append(fmt, pos, pc - pos);
+        size_t end = fmt.find_first_of("%cdiouxXeEfgGaAnps", pc + 1);
+        if (end == std::string::npos) {
+            pos = pc;
+            break;
+        }
+        const std::string spec = fmt.substr(pc, end - pc + 1);
+        const char k = fmt[end];
+        if (std::strchr("cdiouxXp", k)) {
+            at = (at + 3) / 4 * 4;
+            int32_t v;
+            std::memcpy(&v, rec + at, 4);
+            at += 4;
+            snprintf(buf, sizeof(buf), spec.c_str(), v);
+            out += buf;
+        } else if (std::strchr("eEfgGaA", k)) {
+            at = (at + 7) / 8 * 8;
+            double v;
+            std::memcpy(&v, rec + at, 8);
+            at += 8;
+            snprintf(buf, sizeof(buf), spec.c_str(), v);
+            out += buf;
+        } else if (k == '%') {
+            out += "%%"; // lprintf.h:154-156
+        } else {
+            out += spec;
+        }
+        pos = end + 1;
+    }
+    out.append(fmt, pos, std::string::npos);
+    return out;
+}
+int replay_printf(std::ostream &out, const char *p, size_t n) {
+    int count = 0;
+    size_t off = 0;
+    while (off + 8 <= n) {
+        int32_t hdr[2];
+        std::memcpy(hdr, p + off, 8);
+        if (hdr[1] <= 0 || off + (size_t)hdr[1] > n) break;
+        if (hdr[0] == -2) {
+            out << run_printf(p + off);
+            count++;
+        }
+        off += (size_t)hdr[1];
+    }
+    return count;
+}
+
 void manager::flush() {
     if (!d_buf) return;
     int32_t cur[2] = {0, 0};
@@ -114,6 +176,7 @@ void manager::flush() {
     _dropped += cur[1];
     if (cur[0] > 0) {
         hipErrCheck(swarm_hip_memcpy_d2h(host, d_buf, (size_t)cur[0]));
+        replay_printf(std::cerr, (const char *)host, (size_t)cur[0]); // logmanager.cpp:83
         log_writer->process((const char *)host, (size_t)cur[0]);
     }
     if (cur[0] || cur[1]) {
@@ -274,9 +337,16 @@ public:
             a.verbose_on_close_encounter = cfg.optional("verbose_on_close_encounter", false);
         }
         if (MON == SWARM_HIP_MON_LOG_INTERVAL) a.log_interval = cfg.require("log_interval", 0.0); // log_time_interval.hpp:41
+        if (ID == SWARM_HIP_HERMITE) a.rceh = cfg.optional("rceh", 1e-6); // mce_stat_params, mercury_mce_stat.hpp:47
     }
     // = launch_templatized_integrator(this), swarm/gpu/helpers.hpp:216-238: ONE C-ABI call
     virtual void launch_integrator() {
+        // `hermite` is hermite<mce_stat> in this fork (plugins/hermite.cu:40).  mce_stat needs body
+        // attributes 1 and 2, which only exist when the library is built with
+        // NUM_PLANET_ATTRIBUTES >= 3 (make NUM_PLANET_ATTRIBUTES=3); with the default of 1 the
+        // reference's monitor indexes past the Body struct, and `hermite` keeps stop_on_ejection.
+        if (ID == SWARM_HIP_HERMITE)
+            a.monitor = _dens.nbattr >= 3 ? SWARM_HIP_MON_MCE_STAT : SWARM_HIP_MON_EJECTION;
         a.destination_time = _destination_time;
         a.max_iterations = _max_iterations;
         a.log = _logman->get_gpulog();
@@ -285,8 +355,9 @@ public:
     }
 };
 
-// registry names = src/plugins/*.cu.  `hermite` binds stop_on_ejection here (this fork binds
-// mce_stat, plugins/hermite.cu:40).  hermite_log is commented out in the fork.
+// registry names = src/plugins/*.cu.  `hermite` binds mce_stat (plugins/hermite.cu:40) when the
+// build has >= 3 body attributes and stop_on_ejection otherwise (see launch_integrator above).
+// hermite_log is commented out in the fork.
 #define REG(var, ID, MON, name, desc) static integrator_plugin_initializer<hip_integrator<ID, MON> > var(name, desc)
 REG(p_hermite, SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION, "hermite", "Hermite PEC2, fixed time step (MI355X)");
 REG(p_hermite_adap, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION, "hermite_adap", "Hermite PEC2, adaptive time step (MI355X)");

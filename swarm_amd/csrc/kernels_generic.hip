@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
             // monitor (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
             // standard coordinates only for a system that is about to be logged.
             if (MON) {
-                const bool needs_std = mon_pass_one(ms, s, mp);
+                const bool needs_std = mon_pass_one(ms, s, mp, lg);
                 if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
                 mon_pass_two(ms, s, mp);
                 const bool want = mon_need_log(ms, mp);

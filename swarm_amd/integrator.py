@@ -10,7 +10,9 @@ import ctypes as C
 
 import numpy as np
 
-from . import capi
+import sys
+
+from . import capi, gpulog
 from .config import config, key_not_found  # noqa: F401
 from .ensemble import FLT_MAX, DeviceBuffer, DeviceEnsemble, HostEnsemble
 
@@ -24,8 +26,11 @@ class runtime_error(RuntimeError):
 
 
 # plugin id -> (C-ABI integrator, C-ABI monitor); names as registered in src/plugins/*.cu.
-# `hermite` is bound to mce_stat in this fork (plugins/hermite.cu:40); it ships here with the
-# stop_on_ejection monitor that hermite_cpu -- the parity oracle -- uses.
+# `hermite` is bound to mce_stat in this fork (plugins/hermite.cu:40).  That monitor reads and
+# writes body attributes 1 and 2, which do not exist in the reference's default build
+# (NUM_PLANET_ATTRIBUTES=1: the accesses run past the Body struct).  Here `hermite` binds mce_stat
+# when the ensemble carries >= 3 body attributes -- the only case where the reference's behaviour
+# is defined -- and otherwise the stop_on_ejection monitor of hermite_cpu, the parity oracle.
 PLUGINS = {
     "integrator_hermite": (capi.HERMITE, capi.MON_EJECTION),
     "integrator_hermite_adap": (capi.HERMITE_ADAP, capi.MON_EJECTION),
@@ -57,6 +62,8 @@ class LogManager:
         if self.cursor:
             self.cursor.zero()
         self.host = bytearray()
+        self.replay_printf = True   # lprintf lines go to stderr at every flush (logmanager.cpp:79-83)
+        self.printf_count = 0
         self.dropped = 0
         self.bytes_flushed = 0
         # pinned staging buffer: the D2H copy of a flush runs at PCIe speed
@@ -98,6 +105,8 @@ class LogManager:
         if used:
             capi.check(capi.lib.swarm_hip_memcpy_d2h(self._pinned, self.buf.ptr, used))
             self.bytes_flushed += used
+            if self.replay_printf and used:   # logmanager.cpp:83: replay_printf(std::cerr, hlog)
+                self._replay(used)
             if self.writer == "host":
                 self.host += memoryview(self._stage[:used])
             elif self.writer == "count":
@@ -106,6 +115,24 @@ class LogManager:
                 self.writer.process(self._stage[:used].tobytes())
         if used or dropped:
             self.cursor.zero()
+
+
+    def _replay(self, used):
+        view = self._stage[:used]
+        # cheap pre-scan of the headers: only buffers that hold a printf record are formatted
+        off = 0
+        hdr = view.view(np.int32) if used % 4 == 0 else None
+        found = False
+        while hdr is not None and off < used:
+            if hdr[off // 4] == gpulog.MSG_PRINTF:
+                found = True
+                break
+            ln = int(hdr[off // 4 + 1])
+            if ln <= 0:
+                break
+            off += ln
+        if found:
+            self.printf_count += gpulog.replay_printf(sys.stderr, view[off:].tobytes())
 
 
 class Integrator:
@@ -175,6 +202,8 @@ class GpuIntegrator(Integrator):
             a.verbose_on_close_encounter = int(cfg.optional("verbose_on_close_encounter", False))
         if self.mon_id == capi.MON_LOG_INTERVAL:                      # log_time_interval.hpp:39-43
             a.log_interval = cfg.require("log_interval", 0.0)
+        if self.name == "hermite":                                    # mce_stat_params, mercury_mce_stat.hpp:42-53
+            a.rceh = cfg.optional("rceh", 1e-6)
         self.args = a
         self.steps_accepted = None
         self.steps_attempted = None
@@ -233,6 +262,11 @@ class GpuIntegrator(Integrator):
         a.d_steps_accepted = self.steps_accepted.ptr if self.steps_accepted else None
         a.d_steps_attempted = self.steps_attempted.ptr if self.steps_attempted else None
         a.stream = self.stream
+        if self.name == "hermite":
+            a.monitor = capi.MON_MCE_STAT if self._dens.nbattr >= 3 else capi.MON_EJECTION
+            if a.monitor == capi.MON_MCE_STAT and "nbod" in self.cfg and int(self.cfg["nbod"]) != self._dens.nbod:
+                raise runtime_error("mce_stat: nbod=%s in the configuration but the ensemble has %d bodies"
+                                    % (self.cfg["nbod"], self._dens.nbod))
         capi.check(capi.lib.swarm_hip_launch_integrator(self._dens.ref, C.byref(a)))
 
     def core_integrate(self):

@@ -99,3 +99,60 @@ def test_generate_ensemble_matches_oracle(oracle):
         assert (g.pos == o.pos).all() and (g.vel == o.vel).all() and (g.mass == o.mass).all()
         assert (g.body_attr == o.body_attr).all() and (g.state == 0).all()
         np.testing.assert_allclose(g.calc_total_energy(), oracle.total_energy(o), rtol=1e-14)
+
+
+def test_printf_record_layout_and_replay(oracle):
+    """MSG_PRINTF records (gpulog_printf.h, gpulog_msg_layout.h:112-204): header | char fmt[N] at 8 |
+    arguments at natural alignment | pad 16; run_printf (lprintf.h:74-171) formats them.  The oracle
+    writes one through its mce_stat restatement; swarm_amd.gpulog (product host code) replays it."""
+    import io
+    import struct
+    from swarm_amd import gpulog
+    O = oracle
+    e = O.Ensemble(1, 3, 3, 1)
+    g = O.generate(1, 3, planet_mass=1e-3)
+    for k in ("pos", "vel", "mass", "time", "state", "id"):
+        setattr(e, k, getattr(g, k).copy())
+    e.body_attr[:, 0, 0], e.body_attr[:, 1:, 0] = 0.1, 0.05
+    e.id[0] = 7
+    e.pos[0, 1], e.vel[0, 1] = [10, 0, 0], [0, np.sqrt(.1), 0]
+    e.pos[0, 2], e.vel[0, 2] = [10 * np.cos(.05), 10 * np.sin(.05), 0], [np.sqrt(.1) * np.sin(.05), -np.sqrt(.1) * np.cos(.05), 0]
+    log = O.Log(1 << 16)
+    O.integrate(e, O.params("hermite", 2.0, time_step=0.01), O.monitor(kind=O.MON_MCE_STAT, mce_time_step=0.01), log)
+    raw = log.bytes()
+    recs = list(gpulog.records(raw))
+    assert len(recs) == 1 and recs[0][0] == gpulog.MSG_PRINTF
+    rec = recs[0][1]
+    fmt = b"Hitting detected: sysid = %d, i = %d, j = %d, time= %f\n\0"
+    assert rec[8:8 + len(fmt)] == fmt
+    at = (8 + len(fmt) + 3) // 4 * 4
+    assert struct.unpack_from("<iii", rec, at) == (7, 1, 2)
+    at = (at + 12 + 7) // 8 * 8
+    t = struct.unpack_from("<d", rec, at)[0]
+    assert len(rec) == (at + 8 + 15) // 16 * 16 == struct.unpack_from("<i", rec, 4)[0]
+    assert gpulog.run_printf(rec) == "Hitting detected: sysid = 7, i = 1, j = 2, time= %f\n" % t
+    out = io.StringIO()
+    assert gpulog.replay_printf(out, raw) == 1 and out.getvalue() == gpulog.run_printf(rec)
+    assert e.mass[0, 2] == 0 and e.mass[0, 1] == np.float32(2e-3)
+
+
+def test_oracle_mce_swapped_loop_variables_halt_the_system(oracle):
+    """mercury_mce_stat.hpp:312 swaps the loop variables i,j when the lower-index planet is lighter;
+    the pair is then visited again with one mass already zero -> "3 planets in collision" + DISABLED."""
+    O = oracle
+    e = O.Ensemble(1, 3, 3, 1)
+    g = O.generate(1, 3, planet_mass=1e-3)
+    for k in ("pos", "vel", "mass", "time", "state", "id"):
+        setattr(e, k, getattr(g, k).copy())
+    e.body_attr[:, 0, 0], e.body_attr[:, 1:, 0] = 0.1, 0.05
+    e.mass[0, 2] = 2e-3
+    e.pos[0, 1], e.vel[0, 1] = [10, 0, 0], [0, np.sqrt(.1), 0]
+    e.pos[0, 2], e.vel[0, 2] = [10 * np.cos(.05), 10 * np.sin(.05), 0], [np.sqrt(.1) * np.sin(.05), -np.sqrt(.1) * np.cos(.05), 0]
+    log = O.Log(1 << 16)
+    O.integrate(e, O.params("hermite", 2.0, time_step=0.01), O.monitor(kind=O.MON_MCE_STAT, mce_time_step=0.01), log)
+    recs = log.records()
+    assert [r["msgid"] for r in recs] == [-2, -2, 1]
+    assert recs[0]["text"].startswith("Hitting detected: sysid = 0, i = 2, j = 1")
+    assert recs[1]["text"].startswith("3 planets in collision: System halted ! T=")
+    assert recs[2]["state"] == O.ACTIVE and e.state[0] == O.DISABLED   # logged before set_disabled (L345-346)
+    assert e.mass[0, 1] == 0 and e.mass[0, 2] == np.float32(3e-3)

@@ -200,3 +200,32 @@ def test_log_writers_via_cli(tmp_path, oracle):
     assert keys == sorted(keys)
     p = run("query", "-f", base)
     assert len(p.stdout.splitlines()) == 3 * len(orecs)
+
+
+@pytest.mark.gpu
+def test_hermite_binds_mce_stat_when_built_with_three_planet_attributes(tmp_path, oracle):
+    """The reference registers `hermite` as hermite<mce_stat> (plugins/hermite.cu:40).  The CLI built
+    with NUM_PLANET_ATTRIBUTES=3 (swarm_nattr3) runs that monitor: colliding planets merge, the
+    "Hitting detected" lprintf lines are replayed to stderr at flush (logmanager.cpp:83) and the
+    output snapshot carries rce / rphysics in body attributes 1, 2 -- all equal to the oracle's."""
+    O = oracle
+    from test_gpu_mce import retrograde_pair
+    e = retrograde_pair(O, 16)
+    inp, out = tmp_path / "in.txt", tmp_path / "out.txt"
+    O.save_text(e, str(inp))
+    p = subprocess.run([SWARM + "_nattr3", "integrate", "-I", str(inp), "-O", str(out), "integrator=hermite",
+                        "time_step=0.01", "nbod=3", "destination_time=10", "log_writer=host_array"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = O.load_text(str(out))
+    o = O.load_text(str(inp))                      # the CLI saw the 15-digit text, so must the oracle
+    olog = O.Log(1 << 20)
+    O.integrate(o, O.params("hermite", 10.0, time_step=0.01), O.monitor(kind=O.MON_MCE_STAT, mce_time_step=0.01), olog)
+    assert (got.state == o.state).all()
+    np.testing.assert_allclose(got.mass, o.mass, rtol=2e-15)       # "%.15e" text: 16 digits
+    np.testing.assert_allclose(got.time, o.time, rtol=2e-15)
+    np.testing.assert_allclose(got.body_attr, o.body_attr, rtol=1e-12)
+    assert np.abs(got.pos - o.pos).max() < 1e-6
+    want = sorted(r["text"] for r in olog.records() if r["msgid"] == -2)
+    have = sorted(l + "\n" for l in p.stderr.splitlines() if "Hitting detected" in l or "3 planets" in l)
+    assert have == want and len(have) == 16 + 8
