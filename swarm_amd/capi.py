@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libswarm_hip.so")
+# SWARM_HIP_LIB: explicit path of the C-ABI library (kernel-variant experiments, packaging)
+LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswarm_hip.so")
 
 CHUNK = 64
 MIN_NBOD, MAX_NBOD = 3, 8

@@ -415,7 +415,10 @@ __device__ __forceinline__ void mon_init(MonState &ms, const State<N> &s) {
 }
 
 // stop_on_ejection::test_body, monitors/stop_on_ejection.hpp:108-138
-template <int N>
+// VERBOSE (compile time) = the kernel variant that can emit lprintf records: the out-of-line
+// formatter call costs registers in the step loop, so launches without verbose_on_* flags use
+// the variant without it.
+template <int N, bool VERBOSE>
 __device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const MonParams &mp, const LogBuf &lg) {
 #pragma clang fp contract(off)
     const double x = s.p[b][0], y = s.p[b][1], z = s.p[b][2];
@@ -430,7 +433,7 @@ __device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const Mon
     const double epp = 0.5 * speed_sq * r / s.m[b] - 1.;
     const bool parabolic = fabs(epp) < 1e-4;
     if (parabolic || epp > 0) {
-        if (mp.ej_verbose) { // L122-130
+        if (VERBOSE && mp.ej_verbose) { // L122-130
             const double energy = 0.5 * speed_sq - s.m[b] / r;
             if (parabolic)
                 SWH_LPRINTF(lg, "Orbit is nearly parabolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
@@ -445,7 +448,7 @@ __device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const Mon
 }
 
 // stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142
-template <int N>
+template <int N, bool VERBOSE>
 __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp, const LogBuf &lg) {
 #pragma clang fp contract(off)
     const double dx = s.p[i][0] - s.p[j][0], dy = s.p[i][1] - s.p[j][1], dz = s.p[i][2] - s.p[j][2];
@@ -455,7 +458,7 @@ __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const 
     const double a = 0.5 * (ri + ri); // the reference uses body i twice (L130)
     const double rH3 = (s.m[i] + s.m[j]) / (3. * GM) * a * a * a;
     const bool close_encounter = d * d * d < mp.dmin3 * rH3;
-    if (close_encounter && mp.ce_verbose) // L137-141
+    if (VERBOSE && close_encounter && mp.ce_verbose) // L137-141
         SWH_LPRINTF(lg, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", parg(s.number), parg(s.t),
                     parg(j), parg(i), parg(d));
     return close_encounter;
@@ -464,7 +467,7 @@ __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const 
 // pass_one of the bound monitor (stop_on_ejection.hpp:177-193, log_time_interval.hpp:98-111,
 // stop_on_close_encounter.hpp:101-115, composites.hpp:199-200).  Returns need_full_test
 // ("this system needs standard coordinates").
-template <int N>
+template <int N, bool VERBOSE>
 __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, const MonParams &mp,
                                              const LogBuf &lg) {
     bool need_full = false;
@@ -481,7 +484,7 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
     ms.ej_met = false;
     if (mp.ej_any) {
 #pragma unroll
-        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body(s, b, mp, lg);
+        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body<N, VERBOSE>(s, b, mp, lg);
         if (ms.ej_met && mp.ej_log) need_full = true;
     }
     if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && !need_full) { // short-circuit ||
@@ -490,7 +493,7 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
 #pragma unroll
             for (int b = 2; b < N; b++)
 #pragma unroll
-                for (int d = 1; d < b; d++) ms.ce_met = ms.ce_met || ce_check(s, b, d, mp, lg);
+                for (int d = 1; d < b; d++) ms.ce_met = ms.ce_met || ce_check<N, VERBOSE>(s, b, d, mp, lg);
             if (ms.ce_met && mp.ce_log) need_full = true;
         }
     }
@@ -516,17 +519,27 @@ __device__ __forceinline__ bool mon_need_log(const MonState &ms, const MonParams
 // Monitor::operator()(thread_in_system): pass_one, pass_two, log (stop_on_ejection.hpp:140-146).
 // `participate` = this lane really calls the monitor; all lanes of the wave must reach this
 // function together because log_system reserves space wave-wide.
-template <int N>
+template <int N, bool VERBOSE>
 __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonParams &mp,
                                          const LogBuf &lg, bool participate) {
     bool want = false;
     if (participate) {
-        mon_pass_one(ms, s, mp, lg);
+        mon_pass_one<N, VERBOSE>(ms, s, mp, lg);
         mon_pass_two(ms, s, mp);
         want = mon_need_log(ms, mp);
     }
     if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
         if (__any(want)) log_system(lg, s, want);
+}
+
+// kernel variant for a launch: 0 = monitor has nothing to do, 1 = monitor, 2 = monitor + lprintf
+enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2 };
+__host__ __device__ inline bool monitor_is_noop(const MonParams &mp);
+inline int monitor_variant(const MonParams &mp) {
+    if (monitor_is_noop(mp)) return MON_OFF;
+    const bool ej = mp.kind != SWARM_HIP_MON_LOG_INTERVAL && mp.ej_verbose;
+    const bool ce = mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && mp.ce_verbose;
+    return (ej || ce) ? MON_VERBOSE : MON_ON;
 }
 
 __host__ __device__ inline bool monitor_is_noop(const MonParams &mp) {

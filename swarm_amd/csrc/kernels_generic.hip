@@ -95,6 +95,123 @@ __device__ __forceinline__ void drift_kepler(double (&p)[3], double (&v)[3], con
     v[2] = dfdt * z_old + dgdt * vz_old;
 }
 
+// Kepler drift of G planets in lockstep: the same arithmetic per planet as drift_kepler/solvex
+// above (keplerian.hpp:120-236), but the Laguerre iterations of the G planets advance together so
+// that their G independent dependency chains interleave (one lane owns the whole system, so
+// without this every iteration is one long serial chain of FP64 latencies).  A planet whose own
+// loop condition `(i < 7) && !((i > 2) && (x + u == x))` has failed keeps its x (select, no
+// branch).  The Stumpff functions take the series branch of SC_prussing for all planets with one
+// wave-uniform test when every lane is in that regime (|alpha x^2| < 1e-4, the usual case for
+// dt << orbital period), and the general per-planet routine otherwise.
+__device__ __forceinline__ void SC_series(double y, double &S, double &C) { // keplerian.hpp:63-66
+    S = (1.0 / 6.0) * (1.0 - y * (1.0 / 20.0) * (1.0 - y * (1.0 / 42.0) * (1.0 - y * (1.0 / 72.0))));
+    C = (1.0 / 2.0) * (1.0 - y * (1.0 / 12.0) * (1.0 - y * (1.0 / 30.0) * (1.0 - y * (1.0 / 56.0))));
+}
+template <int G>
+__device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], double (&C)[G]) {
+    bool small = true;
+#pragma unroll
+    for (int g = 0; g < G; g++) small = small && (fabs(y[g]) < 1e-4);
+    if (__all(small)) {
+#pragma unroll
+        for (int g = 0; g < G; g++) SC_series(y[g], S[g], C[g]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) SC_prussing(y[g], S[g], C[g]);
+    }
+}
+
+template <int N, int B0, int G>
+__device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqrtGM, const double deltaTime) {
+    const double N_LAG = 5.0;
+    const double smu = sqrtGM;
+    const double GM = sqrtGM * sqrtGM;
+    double r0[G], alpha[G], sig0[G], foo[G], x[G], u[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const double(&p)[3] = s.p[B0 + g];
+        const double(&v)[3] = s.v[B0 + g];
+        r0[g] = fsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        const double v2 = (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const double r0dotv0 = (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]);
+        alpha[g] = (fdiv(2.0, r0[g]) - fdiv(v2, GM));
+        foo[g] = 1.0 - r0[g] * alpha[g];
+        sig0[g] = fdiv(r0dotv0, smu);
+        x[g] = fdiv(sqrtGM * sqrtGM * deltaTime * deltaTime, r0[g]);
+        u[g] = 1.0;
+        live[g] = true;
+    }
+    for (int i = 0; i < 7; i++) {
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            live[g] = live[g] && !((i > 2) && (x[g] + u[g] == x[g]));
+            any = any || live[g];
+        }
+        if (!any) break;
+        double alx2[G], Sp[G], Cp[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) alx2[g] = alpha[g] * (x[g] * x[g]);
+        SC_group<G>(alx2, Sp, Cp);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const double x2 = x[g] * x[g], x3 = x2 * x[g];
+            const double F = sig0[g] * x2 * Cp[g] + foo[g] * x3 * Sp[g] + r0[g] * x[g] - smu * deltaTime;
+            const double dF = sig0[g] * x[g] * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
+            const double ddF = sig0[g] * (1.0 - alx2[g] * Cp[g]) + foo[g] * x[g] * (1.0 - alx2[g] * Sp[g]);
+            double z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
+            z = fsqrt(z);
+            double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
+            if (denom == 0.0) denom = 1e-8;
+            const double un = fdiv(N_LAG * F, denom);
+            u[g] = live[g] ? un : u[g];
+            x[g] = live[g] ? x[g] - un : x[g];
+        }
+    }
+    double alx2[G], Sp[G], Cp[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) alx2[g] = alpha[g] * (x[g] * x[g]);
+    SC_group<G>(alx2, Sp, Cp);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        double(&p)[3] = s.p[B0 + g];
+        double(&v)[3] = s.v[B0 + g];
+        const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
+        const double x_p = x[g], x2 = x_p * x_p, x3 = x2 * x_p;
+        double r = sig0[g] * x_p * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
+        if (r < 0.) r = 0.;
+        const double f_p = 1.0 - fdiv(x2, r0[g]) * Cp[g];
+        const double g_p = deltaTime - fdiv(x3, smu) * Sp[g];
+        const double dgdt = 1.0 - fdiv(x2, r) * Cp[g];
+        double dfdt;
+        if (fabs(g_p) > 1e-8)
+            dfdt = fdiv(f_p * dgdt - 1.0, g_p);
+        else
+            dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
+        p[0] = f_p * x_old + g_p * vx_old;
+        p[1] = f_p * y_old + g_p * vy_old;
+        p[2] = f_p * z_old + g_p * vz_old;
+        v[0] = dfdt * x_old + dgdt * vx_old;
+        v[1] = dfdt * y_old + dgdt * vy_old;
+        v[2] = dfdt * z_old + dgdt * vz_old;
+    }
+}
+
+// all planets 1..N-1, in groups of at most KEPLER_GROUP (register budget: 6 doubles per planet)
+#ifndef SWH_KEPLER_GROUP
+#define SWH_KEPLER_GROUP 2 // measured on MI355X, C4 shard (ms per 1001 steps): G=1 20.7, 2 18.5, 4 19.7, 7 20.9
+#endif
+constexpr int KEPLER_GROUP = SWH_KEPLER_GROUP;
+template <int N, int B0 = 1>
+__device__ __forceinline__ void drift_kepler_all(State<N> &s, const double sqrtGM, const double deltaTime) {
+    if constexpr (B0 < N) {
+        constexpr int G = (N - B0 < KEPLER_GROUP) ? (N - B0) : KEPLER_GROUP;
+        drift_kepler_group<N, B0, G>(s, sqrtGM, deltaTime);
+        drift_kepler_all<N, B0 + G>(s, sqrtGM, deltaTime);
+    }
+}
+
 // ---- MVS coordinate changes: propagators/mvs.hpp:159-190, 195-230 ----------------------------
 template <int N>
 __device__ __forceinline__ void mvs_to_internal(State<N> &s) {
@@ -186,7 +303,7 @@ __device__ __forceinline__ double verlet_timestep(const State<N> &s, const IntPa
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int N, int KIND, bool MON>
+template <int N, int KIND, int MON>
 __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,8 +347,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
-#pragma unroll
-                for (int b = 1; b < N; b++) drift_kepler(s.p[b], s.v[b], sqrtGM, 2.0 * hby2);
+                drift_kepler_all<N>(s, sqrtGM, 2.0 * hby2);
                 acc_only<N, true>(s.p, s.m, acc);
 #pragma unroll
                 for (int b = 1; b < N; b++)
@@ -332,7 +448,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
             // monitor (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
             // standard coordinates only for a system that is about to be logged.
             if (MON) {
-                const bool needs_std = mon_pass_one(ms, s, mp, lg);
+                const bool needs_std = mon_pass_one<N, MON == MON_VERBOSE>(ms, s, mp, lg);
                 if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
                 mon_pass_two(ms, s, mp);
                 const bool want = mon_need_log(ms, mp);
@@ -352,12 +468,14 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
 
 template <int N, int KIND>
 static int launch_n(const LaunchCtx &c) {
-    if (monitor_is_noop(c.mp))
-        hipLaunchKernelGGL((generic_kernel<N, KIND, false>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
-                           c.ip, c.mp, c.lg, c.cnt);
-    else
-        hipLaunchKernelGGL((generic_kernel<N, KIND, true>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
-                           c.ip, c.mp, c.lg, c.cnt);
+#define SWH_LAUNCH_VARIANT(V) \
+    hipLaunchKernelGGL((generic_kernel<N, KIND, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    switch (monitor_variant(c.mp)) {
+    case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
+    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
+    }
+#undef SWH_LAUNCH_VARIANT
     return check_launch("propagator kernel launch");
 }
 

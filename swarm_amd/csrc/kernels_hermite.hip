@@ -8,7 +8,7 @@
 
 namespace swh {
 
-template <int N, bool ADAPTIVE, bool MON>
+template <int N, bool ADAPTIVE, int MON>
 __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
     mon_init(ms, s);
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop,
     // for every system of the ensemble whatever its state.
-    if (ADAPTIVE && MON) mon_call(ms, s, mp, lg, true);
+    if (ADAPTIVE && MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
 
     unsigned long long steps = 0;
     if (s.state == SWARM_HIP_ACTIVE) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
             hermite_step<N>(s, k, a0, j0, a1, j1);
             s.t += h;
             steps++;
-            if (MON) mon_call(ms, s, mp, lg, true);
+            if (MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
             if (s.state == SWARM_HIP_ACTIVE) {
                 // end test: hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
 #pragma clang fp contract(off)
@@ -106,12 +106,14 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 
 template <int N, bool ADAPTIVE>
 static int launch_n(const LaunchCtx &c) {
-    if (monitor_is_noop(c.mp))
-        hipLaunchKernelGGL((hermite_kernel<N, ADAPTIVE, false>), dim3(c.grid), dim3(c.block), 0, c.stream,
-                           c.ens, c.ip, c.mp, c.lg, c.cnt);
-    else
-        hipLaunchKernelGGL((hermite_kernel<N, ADAPTIVE, true>), dim3(c.grid), dim3(c.block), 0, c.stream,
-                           c.ens, c.ip, c.mp, c.lg, c.cnt);
+#define SWH_LAUNCH_VARIANT(V) \
+    hipLaunchKernelGGL((hermite_kernel<N, ADAPTIVE, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    switch (monitor_variant(c.mp)) {
+    case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
+    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
+    }
+#undef SWH_LAUNCH_VARIANT
     return check_launch("hermite kernel launch");
 }
 

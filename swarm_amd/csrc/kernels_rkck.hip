@@ -47,7 +47,7 @@ struct CK {
 //     p_k = pos + h * (c_k * vel + h * sum_j B2[k][j] * k_acc[j]),  B2 = b * b, c_k = rowsum(b[k])
 // which is the same polynomial as the reference's `pos + h*(b[k][0]*k1_vel + ...)` (L158-194)
 // with the products of tableau constants folded at compile time.
-template <int N, bool ADAPTIVE, bool MON>
+template <int N, bool ADAPTIVE, int MON>
 __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                    Counters cnt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
     const int state_in = s.state;
     MonState ms;
     mon_init(ms, s);
-    if (MON) mon_call(ms, s, mp, lg, true); // rkck_integrator.hpp:140, every system
+    if (MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true); // rkck_integrator.hpp:140, every system
 
     const int iteration_count = (int)(ip.destination_time / ip.max_time_step); // L75
     const double dest = ip.destination_time;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
             accepted++;
         }
         // monitor runs only for lanes that accepted (L283); the call itself is wave-wide
-        if (MON) mon_call(ms, s, mp, lg, accept_step);
+        if (MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, accept_step);
         if (accept_step && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
     }
     if (accepted || s.state != state_in) store_state(e, gid, s);
@@ -175,12 +175,14 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 
 template <int N, bool ADAPTIVE>
 static int launch_n(const LaunchCtx &c) {
-    if (monitor_is_noop(c.mp))
-        hipLaunchKernelGGL((rkck_kernel<N, ADAPTIVE, false>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
-                           c.ip, c.mp, c.lg, c.cnt);
-    else
-        hipLaunchKernelGGL((rkck_kernel<N, ADAPTIVE, true>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens,
-                           c.ip, c.mp, c.lg, c.cnt);
+#define SWH_LAUNCH_VARIANT(V) \
+    hipLaunchKernelGGL((rkck_kernel<N, ADAPTIVE, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    switch (monitor_variant(c.mp)) {
+    case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
+    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
+    }
+#undef SWH_LAUNCH_VARIANT
     return check_launch("rkck kernel launch");
 }
 
