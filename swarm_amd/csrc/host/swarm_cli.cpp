@@ -363,8 +363,11 @@ static int real_main(int argc, char *argv[]) {
     pos_threshold = cfg.optional("pos_threshold", 1e-10); // swarm.cpp:572-574
     vel_threshold = cfg.optional("vel_threshold", 1e-10);
     time_threshold = cfg.optional("time_threshold", 1e-10);
-    if (cfg.optional("nogpu", 0) && command != "generate" && command != "convert")
-        ERROR("nogpu=1: this build has no CPU integrators (every integrator plugin runs on the MI355X)");
+    // nogpu=1 selects the reference's CPU plugins (swarm.cpp:454-495, swarm.h:49-60).  This library has
+    // none: the key is accepted, so that the reference's CPU configurations run unchanged, and the
+    // integrator plugins -- the *_cpu names included -- run on the MI355X.
+    if (cfg.optional("nogpu", 0) && command != "generate" && command != "convert" && command != "query" && DEBUG_LEVEL >= 0)
+        cerr << "# nogpu=1 ignored: no CPU integrators in this build, every integrator plugin runs on the MI355X" << endl;
 
     if (command == "integrate") {
         swarm::init(cfg);

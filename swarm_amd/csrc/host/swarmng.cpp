@@ -292,7 +292,7 @@ void integrator::integrate() {
 
 // ---- the plugins: one class, parameterised by kernel and monitor ------------------------------
 // Constructor-time key handling follows each reference constructor (cited inline).
-template <int ID, int MON> class hip_integrator : public gpu::integrator {
+template <int ID, int MON, bool MCE_NAME = false> class hip_integrator : public gpu::integrator {
     swarm_hip_launch_t a;
 
 public:
@@ -345,7 +345,7 @@ public:
         // attributes 1 and 2, which only exist when the library is built with
         // NUM_PLANET_ATTRIBUTES >= 3 (make NUM_PLANET_ATTRIBUTES=3); with the default of 1 the
         // reference's monitor indexes past the Body struct, and `hermite` keeps stop_on_ejection.
-        if (ID == SWARM_HIP_HERMITE)
+        if (MCE_NAME)
             a.monitor = _dens.nbattr >= 3 ? SWARM_HIP_MON_MCE_STAT : SWARM_HIP_MON_EJECTION;
         a.destination_time = _destination_time;
         a.max_iterations = _max_iterations;
@@ -359,7 +359,15 @@ public:
 // build has >= 3 body attributes and stop_on_ejection otherwise (see launch_integrator above).
 // hermite_log is commented out in the fork.
 #define REG(var, ID, MON, name, desc) static integrator_plugin_initializer<hip_integrator<ID, MON> > var(name, desc)
-REG(p_hermite, SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION, "hermite", "Hermite PEC2, fixed time step (MI355X)");
+static integrator_plugin_initializer<hip_integrator<SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION, true> > p_hermite("hermite", "Hermite PEC2, fixed time step (MI355X)");
+// The reference's CPU plugin names (plugins/hermite_cpu.cpp:36-56).  There is no CPU integrator in
+// this library; the names are kept so that the reference's own configurations (test/sample/CPU.cfg,
+// test/integrators/Hermite_CPU.cfg, test/bdb/bdb.sh, `swarm --defaults`) run unchanged.  They are
+// served by the same HIP Hermite kernel, whose arithmetic follows hermite_cpu
+// (integrators/hermite_cpu.hpp) and which reproduces its golden outputs.
+REG(p_hermite_cpu, SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION, "hermite_cpu", "Hermite PEC2 with hermite_cpu's arithmetic, on the MI355X");
+REG(p_hermite_cpu_ce, SWARM_HIP_HERMITE, SWARM_HIP_MON_EJECTION_OR_CLOSE, "hermite_cpu_ejection_or_close_encounter", "hermite_cpu + stop_on_ejection_or_close_encounter");
+REG(p_hermite_cpu_log, SWARM_HIP_HERMITE, SWARM_HIP_MON_LOG_INTERVAL, "hermite_cpu_log", "hermite_cpu + log_time_interval");
 REG(p_hermite_adap, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION, "hermite_adap", "Hermite PEC2, adaptive time step (MI355X)");
 REG(p_hermite_adap_log, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_LOG_INTERVAL, "hermite_adap_log", "hermite_adap + log_time_interval");
 REG(p_hermite_adap_ce, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION_OR_CLOSE, "hermite_adap_close_encounter", "hermite_adap + stop_on_ejection_or_close_encounter");
@@ -729,7 +737,7 @@ void outputConfigSummary(std::ostream &o, config &cfg) { // utils.cpp:140-150
 // `hermite`; this build has no CPU integrators, so the documented value is used.
 config default_config() {
     config cfg;
-    cfg["integrator"] = "hermite";
+    cfg["integrator"] = "hermite_cpu"; // utils.cpp:157; served by the HIP Hermite kernel, see REG below
     cfg["time_step"] = "0.001";
     cfg["log_writer"] = "null";
     cfg["nsys"] = "16";

@@ -33,6 +33,11 @@ class runtime_error(RuntimeError):
 # is defined -- and otherwise the stop_on_ejection monitor of hermite_cpu, the parity oracle.
 PLUGINS = {
     "integrator_hermite": (capi.HERMITE, capi.MON_EJECTION),
+    # the reference's CPU plugin names (plugins/hermite_cpu.cpp:36-56), served by the same HIP kernel:
+    # its arithmetic follows hermite_cpu and reproduces hermite_cpu's golden outputs
+    "integrator_hermite_cpu": (capi.HERMITE, capi.MON_EJECTION),
+    "integrator_hermite_cpu_ejection_or_close_encounter": (capi.HERMITE, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_hermite_cpu_log": (capi.HERMITE, capi.MON_LOG_INTERVAL),
     "integrator_hermite_adap": (capi.HERMITE_ADAP, capi.MON_EJECTION),
     "integrator_hermite_adap_log": (capi.HERMITE_ADAP, capi.MON_LOG_INTERVAL),
     "integrator_hermite_adap_close_encounter": (capi.HERMITE_ADAP, capi.MON_EJECTION_OR_CLOSE),

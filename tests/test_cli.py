@@ -132,8 +132,8 @@ def test_reference_ctest_stability(cfgid):
 @pytest.mark.gpu
 def test_integrate_defaults_and_failure_modes():
     run("integrate", "--defaults")                                   # cmake/test.cmake:12
-    p = run("integrate", "--defaults", "--nogpu", check=False)       # cmake/test.cmake:13: no CPU plugins here
-    assert p.returncode != 0 and "no CPU integrators" in p.stderr
+    p = run("integrate", "--defaults", "--nogpu")                    # cmake/test.cmake:13; hermite_cpu name, HIP kernel
+    assert "nogpu=1 ignored" in p.stderr
     p = run("integrate", "integrator=hermite_log", "time_step=0.001", "nsys=16", "nbod=3", check=False)
     assert p.returncode != 0 and "Integrator hermite_log not found." in p.stderr
     p = run("integrate", "integrator=hermite", "nsys=16", "nbod=3", check=False)
@@ -229,3 +229,41 @@ def test_hermite_binds_mce_stat_when_built_with_three_planet_attributes(tmp_path
     want = sorted(r["text"] for r in olog.records() if r["msgid"] == -2)
     have = sorted(l + "\n" for l in p.stderr.splitlines() if "Hitting detected" in l or "3 planets" in l)
     assert have == want and len(have) == 16 + 8
+
+
+@pytest.mark.gpu
+def test_reference_bdb_script_through_the_gpu_path(tmp_path):
+    """test/bdb/bdb.sh, binary-writer leg, with the script's own configuration (integrator=hermite_cpu_log,
+    nogpu=1 ...): integrate test.4.in.txt, `swarm query -f testing_log.bin`, diff with test.4.ref.txt.
+    The records come from the HIP kernel's device event buffer; the output must equal the reference's
+    golden file byte for byte (528 lines)."""
+    cfg = tmp_path / "testing_log.cfg"
+    log = tmp_path / "testing_log.bin"
+    cfg.write_text("log_output_db=%s\nlog_output=%s\nlog_interval=0.1\ndestination_time=1\nintegrator=hermite_cpu_log\n"
+                   "time_step=0.01\ntime_step_factor=170e-4\nmin_time_step=0.00001\nmax_time_step=0.01\nnogpu=1\n"
+                   % (tmp_path / "testing_log.db", log))
+    run("integrate", "-I", os.path.join(GOLDEN, "bdb", "test.4.in.txt"), "-c", cfg, "log_writer=binary")
+    p = run("query", "-f", log)
+    ref = open(os.path.join(GOLDEN, "bdb", "test.4.ref.txt")).read()
+    assert p.stdout == ref and len(ref.splitlines()) == 528
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8])
+def test_reference_hermite_cpu_cfg_reproduces_goldens(nbod):
+    """test/integrators/Hermite_CPU.cfg is the configuration the golden outputs were generated with
+    (test/integrators/generate.sh).  Run unchanged (integrator=hermite_cpu, nogpu=1) it must reproduce
+    test.N.out.txt at the CLI's default thresholds of 1e-10 (swarm.cpp:572-574), not only ctest's 1e-8."""
+    p = run("test", "-c", os.path.join(INTEG, "Hermite_CPU.cfg"), "-I", os.path.join(INTEG, "test.%d.in.txt" % nbod),
+            "-O", os.path.join(INTEG, "test.%d.out.txt" % nbod), "nbod=%d" % nbod, "-v", "1")
+    assert "Test success" in p.stderr
+
+
+@pytest.mark.gpu
+def test_reference_sample_cpu_cfg(tmp_path, oracle):
+    """BASELINE configs[0]: test/sample/CPU.cfg (hermite_cpu, dt=1e-4, T=1) on test/sample/in.txt must
+    give test/sample/out.txt"""
+    d = os.path.join(GOLDEN, "sample")
+    p = run("test", "-c", os.path.join(d, "CPU.cfg"), "-I", os.path.join(d, "in.txt"), "-O", os.path.join(d, "out.txt"),
+            "-v", "1")
+    assert "Test success" in p.stderr

@@ -1,6 +1,6 @@
 """The reference's Python unit tests (py/tests/trivial.py + abstract.py) against the
-swarmng-compatible module.  The reference runs them with integrator=hermite_cpu (nogpu=1); this
-build has no CPU integrators, so the same scenarios run the GPU `hermite` plugin."""
+swarmng-compatible module, with the reference's own configuration (integrator=hermite_cpu,
+nogpu=1): the hermite_cpu name is served by the HIP Hermite kernel, nogpu is accepted."""
 import math
 import random
 
@@ -106,7 +106,7 @@ def test_basic_integration_energy_conservation():
 
     class T(_IntegrationTest):
         def cfg(self, sw):
-            return sw.config(integrator="hermite", time_step=1e-4)
+            return sw.config(integrator="hermite_cpu", time_step=1e-4, nogpu=1)   # trivial.py:76
 
         def createEnsemble(self, sw):
             return make_test_case(sw, nsys=16, nbod=3, spacing_factor=1.4, seed=14321)
@@ -128,7 +128,7 @@ def test_ejection_test():
         destination_time = 100
 
         def cfg(self, sw):
-            return sw.config(integrator="hermite", time_step=1e-3, deactivate_on_ejection=1, rmax=RMAX)
+            return sw.config(integrator="hermite_cpu", time_step=1e-3, nogpu=1, deactivate_on_ejection=1, rmax=RMAX)
 
         def createEnsemble(self, sw):
             return make_test_case(sw, nsys=20, nbod=6, spacing_factor=1.01, seed=99)
