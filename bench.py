@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=18.0)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the post-run exchange runs "
+                         "over gloo on host copies (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,12 +57,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse_one_gpu else dev   # where collective operands live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     S.capi.check(S.capi.lib.swarm_hip_init(local_rank))
     L = S.capi.lib
 
@@ -118,7 +127,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -138,13 +147,14 @@ def main():
     assert np.allclose(final.time, expect_t, rtol=1e-9), (final.time[:3], expect_t)
     # energy / ejection statistics: one small all-reduce (sum, max, min) over RCCL
     stats = P.allreduce_stats(*P.local_stats(derr, final.state, steps_accepted=nsys * steps_per_pass * args.steps),
-                              dist=dist, device=dev)
+                              dist=dist, device=cdev)
     gather_ms = None
     if dist is not None:
         # final ensemble gather: the device shards are contiguous byte ranges, one all_gather each
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         for t in (tb, td, ti):
+            t = t.to(cdev)
             shards = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(shards, t)
         torch.cuda.synchronize()
@@ -178,8 +188,8 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                      # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE doubled per
                      # the MI355X guide + WRITE_SIZE), profiles/r1/hermite_n3_pmc.json; algorithmic = 340 B/system
-                     "traffic": 22121813 if (nbod, nsys) == (3, 65536) else None,
-                     "kernel": "hermite_kernel<%d,false,false>" % nbod,
+                     "traffic": 22212279 if (nbod, nsys) == (3, 65536) else None,
+                     "kernel": "hermite_kernel<%d,false,0>" % nbod,
                      "kernel_ms_avg": kernel_ms_avg,
                      "flop_per_system_step": flops,
                      "note": "bound is the FP64 vector ALU (not HBM, not MFMA): state is register-resident for "
