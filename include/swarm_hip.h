@@ -52,7 +52,10 @@ enum swarm_hip_integrator {
     SWARM_HIP_EULER = 6,         /* plugins/euler.cu:36, propagators/euler.hpp */
     SWARM_HIP_VERLET = 7,        /* plugins/verlet.cu:35, propagators/verlet.hpp */
     SWARM_HIP_MIDPOINT = 8,      /* plugins/midpoint.cu:35, propagators/midpoint.hpp */
-    SWARM_HIP_HERMITE_PROP = 9   /* plugins/hermite_prop.cu:37, propagators/hermite_propagator.hpp */
+    SWARM_HIP_HERMITE_PROP = 9,  /* plugins/hermite_prop.cu:37, propagators/hermite_propagator.hpp */
+    SWARM_HIP_IRK2 = 10,         /* plugins/irk2.cu:39, integrators/irk2_integrator.hpp (Gauss IRK) */
+    SWARM_HIP_IRK2_CPU = 11      /* plugins/irk2_cpu.cpp:36, integrators/irk2_cpu.hpp: same kernel with
+                                    irk2_cpu's constants (s = 6, uround 1e-16, 50 sweeps, failure rule) */
 };
 
 /* monitor bound to the plugin name */
@@ -94,7 +97,7 @@ typedef struct swarm_hip_launch {
     int32_t block_size;     /* threads per workgroup, multiple of 64; 0 = default;
                                the analogue of system_per_block=                          */
     double destination_time; /*                                   destination_time=      */
-    double time_step;        /* hermite(_prop), mvs, euler, midpoint time_step=          */
+    double time_step;        /* hermite(_prop), mvs, euler, midpoint, irk2 time_step=    */
     double time_step_factor; /* hermite_adap                      time_step_factor=      */
     double min_time_step;    /* hermite_adap, rkck                min_time_step=         */
     double max_time_step;    /* rkck                              max_time_step=         */
@@ -112,6 +115,8 @@ typedef struct swarm_hip_launch {
     double close_approach;                 /* close_approach=                            */
     double log_interval;                   /* log_interval=                              */
     double rceh;                           /* rceh= (mce_stat, default 1e-6)             */
+    int32_t irk2_method;                   /* method= (irk2: stages 2, 4, 6; 0 = 6)      */
+    int32_t reserved0;
     swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
     /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
     uint64_t *d_steps_accepted;

@@ -16,7 +16,7 @@ ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT = 0, 1, 2, 3
 INTEGRATORS = {
     "hermite_cpu": 0, "hermite": 1, "hermite_adap": 2, "rkck_fixed": 3, "rkck_adaptive": 4,
-    "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9,
+    "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9, "irk2_cpu": 10, "irk2": 11,
 }
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -56,7 +56,7 @@ class _Par(C.Structure):
                 ("destination_time", C.c_double), ("time_step", C.c_double),
                 ("time_step_factor", C.c_double), ("min_time_step", C.c_double),
                 ("max_time_step", C.c_double), ("error_tolerance", C.c_double),
-                ("max_timestep", C.c_double), ("timestep_scale", C.c_double)]
+                ("max_timestep", C.c_double), ("timestep_scale", C.c_double), ("irk2_method", C.c_int32)]
 
 
 class _Cnt(C.Structure):
@@ -135,9 +135,9 @@ def monitor(kind=MON_EJECTION, rmax=FLT_MAX, deactivate_on_ejection=0, log_on_ej
 
 def params(integrator, destination_time, max_iterations=10000000, time_step=0.0, time_step_factor=0.0,
            min_time_step=0.0, max_time_step=0.0, error_tolerance=0.0, max_timestep=0.0,
-           timestep_scale=0.0):
+           timestep_scale=0.0, method=0):
     return _Par(INTEGRATORS[integrator], max_iterations, destination_time, time_step, time_step_factor,
-                min_time_step, max_time_step, error_tolerance, max_timestep, timestep_scale)
+                min_time_step, max_time_step, error_tolerance, max_timestep, timestep_scale, method)
 
 
 class Log:

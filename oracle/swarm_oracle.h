@@ -74,7 +74,9 @@ enum {
     ORC_INT_EULER = 6,
     ORC_INT_VERLET = 7,
     ORC_INT_MIDPOINT = 8,
-    ORC_INT_HERMITE_PROP = 9 /* propagators/hermite_propagator.hpp under generic<> */
+    ORC_INT_HERMITE_PROP = 9, /* propagators/hermite_propagator.hpp under generic<> */
+    ORC_INT_IRK2_CPU = 10,    /* integrators/irk2_cpu.hpp (CPU arithmetic order, s = 6)     */
+    ORC_INT_IRK2 = 11         /* integrators/irk2_integrator.hpp (GPU arithmetic order)     */
 };
 
 typedef struct {
@@ -88,6 +90,7 @@ typedef struct {
     double error_tolerance;   /* rkck */
     double max_timestep;      /* verlet: max_timestep */
     double timestep_scale;    /* verlet */
+    int32_t irk2_method;      /* irk2: method= (number of stages 2, 4 or 6; 0 = default 6) */
 } orc_params;
 
 /* per-system counters, optional (may be NULL) */

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswa
 CHUNK = 64
 MIN_NBOD, MAX_NBOD = 3, 8
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
-HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP = range(1, 10)
+HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP, IRK2, IRK2_CPU = range(1, 12)
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT = 0, 1, 2, 3
 
 
@@ -36,7 +36,7 @@ class LaunchStruct(C.Structure):
                 ("deactivate_on_ejection", C.c_int32), ("log_on_ejection", C.c_int32),
                 ("verbose_on_ejection", C.c_int32), ("deactivate_on_close_encounter", C.c_int32),
                 ("log_on_close_encounter", C.c_int32), ("verbose_on_close_encounter", C.c_int32),
-                ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double),
+                ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double), ("irk2_method", C.c_int32), ("reserved0", C.c_int32),
                 ("log", LogStruct),
                 ("d_steps_accepted", C.c_void_p), ("d_steps_attempted", C.c_void_p),
                 ("stream", C.c_void_p)]

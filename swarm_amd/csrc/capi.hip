@@ -339,6 +339,8 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     switch (a->integrator) {
     case SWARM_HIP_HERMITE:
     case SWARM_HIP_HERMITE_PROP:
+    case SWARM_HIP_IRK2:
+    case SWARM_HIP_IRK2_CPU:
     case SWARM_HIP_EULER:
     case SWARM_HIP_MIDPOINT:
     case SWARM_HIP_MVS:
@@ -363,8 +365,8 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     default:
         break;
     }
-    if (a->monitor == SWARM_HIP_MON_MCE_STAT && a->integrator != SWARM_HIP_HERMITE) {
-        set_error("monitor mce_stat is bound to integrator hermite only (plugins/hermite.cu:40)");
+    if (a->monitor == SWARM_HIP_MON_MCE_STAT && a->integrator != SWARM_HIP_HERMITE && a->integrator != SWARM_HIP_IRK2) {
+        set_error("monitor mce_stat is bound to the integrators hermite and irk2 only (plugins/hermite.cu:40, irk2.cu:39)");
         return SWARM_HIP_EINVAL;
     }
     switch (a->integrator) {
@@ -383,6 +385,10 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     case SWARM_HIP_MIDPOINT:
     case SWARM_HIP_HERMITE_PROP:
         return launch_generic(c, a->integrator);
+    case SWARM_HIP_IRK2:
+        return launch_irk2(c, a->irk2_method ? a->irk2_method : 6, false);
+    case SWARM_HIP_IRK2_CPU:
+        return launch_irk2(c, 6, true);
     default:
         set_error("unknown integrator id %d", a->integrator);
         return SWARM_HIP_EINVAL;

@@ -303,7 +303,7 @@ public:
         int spb = cfg.optional("system_per_block", 0); // the reference's block-shape knob
         if (spb > 0) a.block_size = std::max(64, std::min(256, (spb + 63) / 64 * 64));
         if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_MVS || ID == SWARM_HIP_EULER || ID == SWARM_HIP_MIDPOINT ||
-            ID == SWARM_HIP_HERMITE_PROP)
+            ID == SWARM_HIP_HERMITE_PROP || ID == SWARM_HIP_IRK2 || ID == SWARM_HIP_IRK2_CPU)
             a.time_step = cfg.require("time_step", 0.0); // hermite_integrator.hpp:44-46, mvs.hpp:41-43, ...
         if (ID == SWARM_HIP_HERMITE_ADAP) { // hermite_adap.hpp:44-47
             a.time_step_factor = cfg.require("time_step_factor", 0.0);
@@ -337,7 +337,8 @@ public:
             a.verbose_on_close_encounter = cfg.optional("verbose_on_close_encounter", false);
         }
         if (MON == SWARM_HIP_MON_LOG_INTERVAL) a.log_interval = cfg.require("log_interval", 0.0); // log_time_interval.hpp:41
-        if (ID == SWARM_HIP_HERMITE) a.rceh = cfg.optional("rceh", 1e-6); // mce_stat_params, mercury_mce_stat.hpp:47
+        if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_IRK2) a.rceh = cfg.optional("rceh", 1e-6); // mce_stat_params, mercury_mce_stat.hpp:47
+        if (ID == SWARM_HIP_IRK2) a.irk2_method = cfg.optional("method", 6); // irk2_integrator.hpp:53
     }
     // = launch_templatized_integrator(this), swarm/gpu/helpers.hpp:216-238: ONE C-ABI call
     virtual void launch_integrator() {
@@ -380,6 +381,8 @@ REG(p_mvs_ce, SWARM_HIP_MVS, SWARM_HIP_MON_EJECTION_OR_CLOSE, "mvs_close_encount
 REG(p_euler, SWARM_HIP_EULER, SWARM_HIP_MON_EJECTION, "euler", "This is the integrator based on euler propagator");
 REG(p_verlet, SWARM_HIP_VERLET, SWARM_HIP_MON_EJECTION, "verlet", "This is the integrator based on verlet propagator");
 REG(p_midpoint, SWARM_HIP_MIDPOINT, SWARM_HIP_MON_EJECTION, "midpoint", "This is the integrator based on midpoint propagator");
+static integrator_plugin_initializer<hip_integrator<SWARM_HIP_IRK2, SWARM_HIP_MON_EJECTION, true> > p_irk2("irk2", "Implicit Runge-Kutta w/ Fixed Time step (MI355X)");
+REG(p_irk2_cpu, SWARM_HIP_IRK2_CPU, SWARM_HIP_MON_EJECTION, "irk2_cpu", "Implicit Runge-Kutta with irk2_cpu's constants, on the MI355X");
 REG(p_hermite_prop, SWARM_HIP_HERMITE_PROP, SWARM_HIP_MON_EJECTION, "hermite_prop", "Propagator version of Hermite integrator");
 
 // ---- swarm::init -----------------------------------------------------------------------------

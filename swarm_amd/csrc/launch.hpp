@@ -24,6 +24,8 @@ int launch_hermite(const LaunchCtx &c, bool adaptive);
 int launch_hermite_mce(const LaunchCtx &c); // `hermite` + mce_stat (plugins/hermite.cu:40)
 int launch_rkck(const LaunchCtx &c, bool adaptive);
 int launch_generic(const LaunchCtx &c, int integrator);
+// Gauss IRK; method = stages (2, 4, 6); cpu_rules = irk2_cpu's iteration constants and failure rule
+int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules);
 
 // nbod -> template dispatch, the analogue of choose<> (swarm/gpu/helpers.hpp:97-107,216-238)
 #define SWH_DISPATCH_NBOD(nbod, CALL)                                      \

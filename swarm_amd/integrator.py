@@ -51,6 +51,9 @@ PLUGINS = {
     "integrator_verlet": (capi.VERLET, capi.MON_EJECTION),
     "integrator_midpoint": (capi.MIDPOINT, capi.MON_EJECTION),
     "integrator_hermite_prop": (capi.HERMITE_PROP, capi.MON_EJECTION),
+    # Gauss implicit Runge-Kutta: plugins/irk2.cu:39 (bound to mce_stat like `hermite`), plugins/irk2_cpu.cpp:36
+    "integrator_irk2": (capi.IRK2, capi.MON_EJECTION),
+    "integrator_irk2_cpu": (capi.IRK2_CPU, capi.MON_EJECTION),
 }
 
 
@@ -177,7 +180,7 @@ class GpuIntegrator(Integrator):
         if spb:
             a.block_size = max(64, min(256, (spb + 63) // 64 * 64))
         # constructor-time key checks follow each reference ctor
-        if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT, capi.HERMITE_PROP):
+        if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT, capi.HERMITE_PROP, capi.IRK2, capi.IRK2_CPU):
             a.time_step = cfg.require("time_step", 0.0)      # hermite_integrator.hpp:44-46 etc.
         if self.int_id == capi.HERMITE_ADAP:
             a.time_step_factor = cfg.require("time_step_factor", 0.0)  # hermite_adap.hpp:45-46
@@ -207,8 +210,10 @@ class GpuIntegrator(Integrator):
             a.verbose_on_close_encounter = int(cfg.optional("verbose_on_close_encounter", False))
         if self.mon_id == capi.MON_LOG_INTERVAL:                      # log_time_interval.hpp:39-43
             a.log_interval = cfg.require("log_interval", 0.0)
-        if self.name == "hermite":                                    # mce_stat_params, mercury_mce_stat.hpp:42-53
+        if self.name in ("hermite", "irk2"):                          # mce_stat_params, mercury_mce_stat.hpp:42-53
             a.rceh = cfg.optional("rceh", 1e-6)
+        if self.int_id == capi.IRK2:                                  # irk2_integrator.hpp:53
+            a.irk2_method = cfg.optional("method", 6)
         self.args = a
         self.steps_accepted = None
         self.steps_attempted = None
@@ -267,7 +272,7 @@ class GpuIntegrator(Integrator):
         a.d_steps_accepted = self.steps_accepted.ptr if self.steps_accepted else None
         a.d_steps_attempted = self.steps_attempted.ptr if self.steps_attempted else None
         a.stream = self.stream
-        if self.name == "hermite":
+        if self.name in ("hermite", "irk2"):
             a.monitor = capi.MON_MCE_STAT if self._dens.nbattr >= 3 else capi.MON_EJECTION
             if a.monitor == capi.MON_MCE_STAT and "nbod" in self.cfg and int(self.cfg["nbod"]) != self._dens.nbod:
                 raise runtime_error("mce_stat: nbod=%s in the configuration but the ensemble has %d bodies"

@@ -100,7 +100,8 @@ def test_query_reproduces_reference_bdb_golden(tmp_path, oracle):
 
 
 # ---------------------------------------------------------------- GPU side
-CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-7)]
+CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-7),
+         ("irk2", 1e-8)]
 
 
 @pytest.mark.gpu
@@ -266,4 +267,14 @@ def test_reference_sample_cpu_cfg(tmp_path, oracle):
     d = os.path.join(GOLDEN, "sample")
     p = run("test", "-c", os.path.join(d, "CPU.cfg"), "-I", os.path.join(d, "in.txt"), "-O", os.path.join(d, "out.txt"),
             "-v", "1")
+    assert "Test success" in p.stderr
+
+
+@pytest.mark.gpu
+def test_reference_irk2_cpu_cfg_one_million_steps():
+    """test/integrators/irk2_cpu.cfg unchanged: integrator=irk2_cpu, time_step=0.000001 (10^6 implicit steps to
+    T=1), nogpu=1 -- the reference's ctest runs it against the goldens at 1e-8 (irk2_cpu is enabled by default)."""
+    p = run("test", "-c", os.path.join(INTEG, "irk2_cpu.cfg"), "-I", os.path.join(INTEG, "test.3.in.txt"), "-O",
+            os.path.join(INTEG, "test.3.out.txt"), "nbod=3", "destination_time=1", "pos_threshold=1E-8",
+            "vel_threshold=1E-8", "-v", "1")
     assert "Test success" in p.stderr

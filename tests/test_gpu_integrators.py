@@ -27,6 +27,8 @@ CASES = {
     "verlet": ({"max_timestep": "1e-4", "timestep_scale": "1.0"}, dict(max_timestep=1e-4, timestep_scale=1.0), 1.0),
     "mvs": ({"time_step": "0.01"}, dict(time_step=0.01), 1.0),
     "hermite_prop": ({"time_step": "0.003"}, dict(time_step=0.003), 1.0),
+    "irk2": ({"time_step": "0.01"}, dict(time_step=0.01), 1.0),
+    "irk2_cpu": ({"time_step": "0.005"}, dict(time_step=0.005), 1.0),
 }
 
 
@@ -58,7 +60,7 @@ def test_integrator_vs_oracle(gpu, oracle, name, nbod):
     assert rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
     assert np.abs(h.pos[:, 0] - e.pos[:, 0]).max() < TOL and np.abs(h.vel[:, 0] - e.vel[:, 0]).max() < TOL
     gacc, gatt = integ.step_counts()
-    if name in ("euler", "midpoint", "mvs", "rkck_fixed", "hermite_prop"):
+    if name in ("euler", "midpoint", "mvs", "rkck_fixed", "hermite_prop", "irk2", "irk2_cpu"):
         # fixed step: identical h sequence -> identical step counts and bit-identical times
         assert (gacc == acc.astype(np.uint64)).all() and (gatt == att.astype(np.uint64)).all()
         assert (h.time == e.time).all()
@@ -78,6 +80,8 @@ def test_integrator_vs_oracle(gpu, oracle, name, nbod):
     ("rkck_fixed", {"time_step": "0.0001", "min_time_step": "0.0001", "max_time_step": "0.0001",
                     "error_tolerance": "1e-27"}),
     ("mvs", {"time_step": "0.0003"}),
+    ("irk2", {"time_step": "0.01", "nbod": "3"}),            # test/integrators/irk2.cfg
+    ("irk2_cpu", {"time_step": "0.0001", "nogpu": "1"}),     # irk2_cpu.cfg has 1e-6 (10^6 steps); same bar
 ])
 @pytest.mark.parametrize("nbod", [3, 6])
 def test_reference_ctest_scenarios(gpu, oracle, name, cfg, nbod):
@@ -118,3 +122,34 @@ def test_c3_rkck_adaptive_nbod6_divergent_steps(gpu, oracle):
     assert np.abs(gatt.astype(np.int64) - att).max() <= 3
     np.testing.assert_allclose(h.time, e.time, rtol=1e-12)
     assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-9 and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < 1e-9
+
+
+def test_irk2_no_convergence_disables_the_system_and_says_so(gpu, oracle):
+    """irk2_integrator.hpp:231-239: 100 sweeps without convergence -> lprintf "no convergence of iteration: 100",
+    set_disabled -- the update of that step is still applied (L251-269).  time_step = 10 on a planet with a period
+    of 2.2 diverges for every system; irk2_cpu (50 sweeps, irk2_cpu.hpp:246-250) returns instead: nothing is
+    stored, the system stays ACTIVE at t = 0 and the host's attempt loop gives up after max_attempts."""
+    S, O = gpu, oracle
+    e = perturbed(O, 70, 3, seed=4)
+    e.pos *= 0.05
+    e.vel /= np.sqrt(0.05)
+    h = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "irk2", "time_step": "10"}))
+    integ.set_ensemble(h)
+    integ.set_destination_time(40.0)
+    lm = S.LogManager(1 << 20, "host")
+    lm.replay_printf = False
+    integ.set_log_manager(lm)
+    integ.integrate()
+    o = e.clone()
+    olog = O.Log(1 << 20)
+    O.integrate(o, O.params("irk2", 40.0, time_step=10.0), O.monitor(), olog)
+    assert (h.state == O.DISABLED).all() and (o.state == O.DISABLED).all() and (h.time == 10.0).all()
+    texts = [r["text"] for r in O.parse_log(bytes(lm.host))]
+    assert texts == ["no convergence of iteration: 100\n"] * 70 == [r["text"] for r in olog.records()]
+    h2 = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "irk2_cpu", "time_step": "10", "max_attempts": "3"}))
+    integ.set_ensemble(h2)
+    integ.set_destination_time(40.0)
+    assert integ.integrate() == 3
+    assert (h2.state == O.ACTIVE).all() and (h2.time == 0.0).all() and (h2.pos == e.pos).all()

@@ -135,7 +135,7 @@ def test_mce_refuses_other_integrators_and_missing_attributes(gpu):
     d3 = S.DeviceEnsemble(64, 3, 3, 1)
     a.integrator = S.capi.MVS
     assert S.capi.lib.swarm_hip_launch_integrator(d3.ref, __import__("ctypes").byref(a)) != 0
-    assert b"hermite only" in S.capi.lib.swarm_hip_last_error()
+    assert b"hermite and irk2 only" in S.capi.lib.swarm_hip_last_error()
 
 
 @pytest.mark.parametrize("name,cfg,okw", [
@@ -179,3 +179,23 @@ def test_verbose_on_close_encounter_lprintf_records(gpu, oracle):
     ot, _ = texts(O, olog.bytes())
     assert gt == ot and len(gt) == (o.state == O.DISABLED).sum()
     assert all(t.startswith("Close apporach detected: sys=") for t in gt)
+
+
+def test_irk2_binds_mce_stat_too(gpu, oracle):
+    """plugins/irk2.cu:39: irk2< mce_stat<L>, GravitationAcc >.  mce_stat only looks at a pair when the bounding
+    boxes of the two paths over ONE step overlap (boxes grown by 1.2 rce, rce = Hill radius * rceh); with the
+    default rceh=1e-6 that is the step in which the point masses pass through each other, where irk2's fixed-point
+    iteration cannot converge.  rceh=1 and planet radii of 0.5 make the hit register at a separation of 0.5,
+    a well-conditioned merge: states, masses, halting steps and every lprintf line equal the oracle's."""
+    S, O = gpu, oracle
+    e = retrograde_pair(O, 32)
+    e.body_attr[:, 1:, 0] = 0.5
+    h, lm, o, olog = run(S, O, e, {"integrator": "irk2", "time_step": "0.01", "rceh": "1.0"}, 10.0, dict(time_step=0.01),
+                         O.monitor(kind=O.MON_MCE_STAT, mce_time_step=0.01, rceh=1.0))
+    assert (h.state == o.state).all() and (h.mass == o.mass).all() and (h.time == o.time).all()
+    assert (o.state[0::2] == O.INACTIVE).all() and (o.state[1::2] == O.DISABLED).all()
+    assert rel_diff(h.pos, o.pos) < 1e-9 and np.abs(h.vel - o.vel).max() < 1e-10
+    np.testing.assert_allclose(h.body_attr, o.body_attr, rtol=1e-12)
+    gt, gs = texts(O, lm.host)
+    ot, os_ = texts(O, olog.bytes())
+    assert gt == ot and len(gt) == 48 and len(gs) == len(os_) == 16

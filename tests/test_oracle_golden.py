@@ -166,3 +166,19 @@ def test_close_orbits_ejection_fixture(oracle):
     d = os.path.join(GOLDEN, "monitors", "close_orbits")
     ref = O.load_text(os.path.join(d, "HermiteEjection.4.out.txt"))
     assert int((ref.state == O.DISABLED).sum()) == 11
+
+
+@pytest.mark.parametrize("name,dt,kw", [("irk2_cpu", 1e-3, {}), ("irk2", 0.01, {}), ("irk2", 0.01, {"method": 4}),
+                                        ("irk2", 1e-3, {"method": 2})])
+@pytest.mark.parametrize("nbod", [3, 5, 8])
+def test_irk2_restatements_meet_the_reference_ctest_bar(oracle, name, dt, kw, nbod):
+    """irk2_cpu is enabled by default and has a cfg (test/integrators/irk2_cpu.cfg), so the reference's
+    ctest runs it against the hermite_cpu goldens at 1e-8 (cmake/test_integrators.cmake:20-39); irk2.cfg
+    does the same for the GPU plugin when it is enabled.  The order-12/8/4 Gauss methods land within
+    1e-10 of the goldens."""
+    O = oracle
+    e = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
+    ref = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.out.txt" % nbod))
+    O.integrate(e, O.params(name, 1.0, time_step=dt, **kw), threads=4)
+    pd, vd, td = O.compare(e, ref)
+    assert pd < 1e-10 and vd < 1e-12 and td == 0 and (e.state == ref.state).all()
