@@ -326,6 +326,12 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
         set_error("log.d_buf given without log.d_cursor");
         return SWARM_HIP_EINVAL;
     }
+    // the cursor is an int32 that lanes bump before they check the capacity (as gpulog does,
+    // bits/gpulog_write.h:14-22): keep room for the transient overshoot of every resident lane
+    if (c.lg.buf && (c.lg.cap < 0 || c.lg.cap > 0x70000000)) {
+        set_error("log.capacity=%d must be in [0, 0x70000000] bytes", c.lg.cap);
+        return SWARM_HIP_EINVAL;
+    }
     c.cnt.accepted = reinterpret_cast<unsigned long long *>(a->d_steps_accepted);
     c.cnt.attempted = reinterpret_cast<unsigned long long *>(a->d_steps_attempted);
     c.block = a->block_size > 0 ? a->block_size : 256;
