@@ -63,9 +63,11 @@ enum swarm_hip_monitor {
     SWARM_HIP_MON_EJECTION = 0,          /* monitors/stop_on_ejection.hpp */
     SWARM_HIP_MON_LOG_INTERVAL = 1,      /* monitors/log_time_interval.hpp (`*_log` names) */
     SWARM_HIP_MON_EJECTION_OR_CLOSE = 2, /* monitors/composites.hpp:145-222 (`*_close_encounter`) */
-    SWARM_HIP_MON_MCE_STAT = 3           /* monitors/mercury_mce_stat.hpp: what plugins/hermite.cu:40 binds
+    SWARM_HIP_MON_MCE_STAT = 3,          /* monitors/mercury_mce_stat.hpp: what plugins/hermite.cu:40 binds
                                             to `hermite`; SWARM_HIP_HERMITE only, needs nbattr >= 3
                                             (radius, rce, rphysics) and nsattr >= 1 */
+    SWARM_HIP_MON_LOG_TRANSIT = 4       /* monitors/log_transit.hpp (`hermite_adap_transit`,
+                                            plugins/hermite_adap.cu:61); SWARM_HIP_HERMITE_ADAP only */
 };
 
 typedef struct swarm_hip_ensemble {
@@ -116,7 +118,11 @@ typedef struct swarm_hip_launch {
     double log_interval;                   /* log_interval=                              */
     double rceh;                           /* rceh= (mce_stat, default 1e-6)             */
     int32_t irk2_method;                   /* method= (irk2: stages 2, 4, 6; 0 = 6)      */
+    int32_t log_transits;                  /* log_transits= (log_transit, default 1)     */
+    int32_t log_occultations;              /* log_occultations= (default 0)              */
     int32_t reserved0;
+    double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
+                                              monitor's dt is time_step=                 */
     swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
     /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
     uint64_t *d_steps_accepted;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
-MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT = 0, 1, 2, 3
+MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT, MON_LOG_TRANSIT = 0, 1, 2, 3, 4
 INTEGRATORS = {
     "hermite_cpu": 0, "hermite": 1, "hermite_adap": 2, "rkck_fixed": 3, "rkck_adaptive": 4,
     "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9, "irk2_cpu": 10, "irk2": 11,
@@ -44,7 +44,8 @@ class _Mon(C.Structure):
                 ("log_interval", C.c_double), ("close_approach", C.c_double),
                 ("deactivate_on_close_encounter", C.c_int32), ("log_on_close_encounter", C.c_int32),
                 ("verbose_on_close_encounter", C.c_int32), ("rceh", C.c_double),
-                ("mce_time_step", C.c_double)]
+                ("mce_time_step", C.c_double), ("tr_tol", C.c_double), ("tr_dt", C.c_double),
+                ("tr_log_transit", C.c_int32), ("tr_log_occultation", C.c_int32)]
 
 
 class _Log(C.Structure):
@@ -127,10 +128,11 @@ def generate(nsys, nbod, spacing_factor=1.4, planet_mass=1e-4, ejection_factor=1
 def monitor(kind=MON_EJECTION, rmax=FLT_MAX, deactivate_on_ejection=0, log_on_ejection=0,
             verbose_on_ejection=0, log_interval=0.0, close_approach=0.0,
             deactivate_on_close_encounter=0, log_on_close_encounter=0, verbose_on_close_encounter=0,
-            rceh=1e-6, mce_time_step=0.0):
+            rceh=1e-6, mce_time_step=0.0, log_transit_tol=2e-8, transit_dt=0.0, log_transits=1, log_occultations=0):
     return _Mon(kind, rmax, deactivate_on_ejection, log_on_ejection, verbose_on_ejection,
                 log_interval, close_approach, deactivate_on_close_encounter, log_on_close_encounter,
-                verbose_on_close_encounter, rceh, mce_time_step)
+                verbose_on_close_encounter, rceh, mce_time_step, log_transit_tol, transit_dt, log_transits,
+                log_occultations)
 
 
 def params(integrator, destination_time, max_iterations=10000000, time_step=0.0, time_step_factor=0.0,
@@ -167,6 +169,11 @@ def parse_log(raw):
             rec["bodies"] = bod[:, :7].copy()
             rec["body_id"] = np.frombuffer(raw, dtype=np.int32, count=16 * nb,
                                            offset=off + 32).reshape(nb, 16)[:, 14].copy()
+        elif msgid in (15, 16):                # EVT_TRANSIT / EVT_OCCULTATION, log/log.hpp:215-217, 261-265
+            rec["time"] = float(np.frombuffer(raw, dtype=np.float64, count=1, offset=off + 8)[0])
+            sid, bod = np.frombuffer(raw, dtype=np.int32, count=2, offset=off + 16)
+            b, vproj = np.frombuffer(raw, dtype=np.float64, count=2, offset=off + 24)
+            rec.update(sys=int(sid), body=int(bod), b=float(b), vproj=float(vproj))
         elif msgid == -2:                      # MSG_PRINTF, gpulog_constants.h:35
             rec["text"] = run_printf(raw[off:off + int(ln)])
         out.append(rec)

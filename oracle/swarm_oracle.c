@@ -523,6 +523,80 @@ static void mce_call(monitor *m, double c_pos[][3], double c_vel[][3]) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* log_transit, monitors/log_transit.hpp (USE_WORKS 1, L32).  acc/jerk = the integrator's last force
+ * evaluation, which the reference reads back from the gravitation shared memory (L216-227); on the
+ * first call (hermite_adap.hpp:130, before any force evaluation) that memory is uninitialised in
+ * the reference -- the restatement passes the forces of the initial state.  PARITY UNPINNED.    */
+static void log_event_transit(orc_log *log, int evt, double T, int sys, int j, double b, double vproj) {
+    uint8_t *r = log_reserve(log, 48); /* log::event, log/log.hpp:261-265: T@8 sys@16 j@20 b@24 vproj@32 */
+    if (!r) return;
+    int32_t len = 48;
+    memcpy(r, &evt, 4), memcpy(r + 4, &len, 4), memcpy(r + 8, &T, 8), memcpy(r + 16, &sys, 4);
+    memcpy(r + 20, &j, 4), memcpy(r + 24, &b, 8), memcpy(r + 32, &vproj, 8);
+}
+
+/* check_in_transit(thread, i, j, dt), L256-386, with calc_transit_time_works, L213-253 */
+static int transit_check(const monitor *m, int i, int j, double acc[][3], double jerk[][3]) {
+    const sysref *s = m->s;
+    const orc_monitor *p = m->p;
+    const double dt = p->tr_dt;
+    double depth = s->pos[j][2] - s->pos[i][2];
+    if (!p->tr_log_occultation && (depth < 0.)) return 0;
+    if (!p->tr_log_transit && (depth > 0.)) return 0;
+    double dx[2] = {s->pos[j][0] - s->pos[i][0], s->pos[j][1] - s->pos[i][1]};
+    double dv[2] = {s->vel[j][0] - s->vel[i][0], s->vel[j][1] - s->vel[i][1]};
+    double b2begin = dx[0] * dx[0] + dx[1] * dx[1];
+    double db2dt = 2. * (dx[0] * dv[0] + dx[1] * dv[1]);
+    double radi = (s->nbattr >= 1) ? BATTR(s, i, 0) : 0.;
+    double radj = (s->nbattr >= 1) ? BATTR(s, j, 0) : 0.;
+    double lim = (radi + radj) * (1. + p->tr_tol);
+    if (fmin(b2begin - 0.5 * dt * db2dt, b2begin + 0.5 * dt * db2dt) > lim * lim) return 0;
+    double dt_min_b2, b, vproj;
+    {
+        double da[2] = {acc[j][0] - acc[i][0], acc[j][1] - acc[i][1]};
+        double dj[2] = {jerk[j][0] - jerk[i][0], jerk[j][1] - jerk[i][1]};
+        double d2b2dt2 = 2. * (dv[0] * dv[0] + dv[1] * dv[1] + dx[0] * da[0] + dx[1] * da[1]);
+        double d3b2dt3 = 6. * (dv[0] * da[0] + dv[1] * da[1]) + 2. * (dx[0] * dj[0] + dx[1] * dj[1]);
+        double dt_try = -db2dt / d2b2dt2;
+        dt_try = -db2dt / (d2b2dt2 + 0.5 * dt_try * d3b2dt3);
+        if ((dt_try < -0.5 * dt) || (dt_try > 0.5 * dt)) {
+            dt_min_b2 = dt_try, b = -1., vproj = -1.;
+        } else {
+            dt_min_b2 = 0.;
+            double min_b2 = b2begin;
+            dx[0] += dt_try * (dv[0] + dt_try * 0.5 * (da[0] + dt_try * dj[0] / 3.));
+            dx[1] += dt_try * (dv[1] + dt_try * 0.5 * (da[1] + dt_try * dj[1] / 3.));
+            double b2 = (dx[0] * dx[0] + dx[1] * dx[1]);
+            if (b2 < min_b2) min_b2 = b2, dt_min_b2 = dt_try;
+            b = (min_b2 > 0) ? sqrt(min_b2) : -sqrt(-min_b2);
+            dv[0] += dt_min_b2 * (da[0] + 0.5 * dt_min_b2 * dj[0]);
+            dv[1] += dt_min_b2 * (da[1] + 0.5 * dt_min_b2 * dj[1]);
+            vproj = sqrt(dv[0] * dv[0] + dv[1] * dv[1]);
+        }
+    }
+    if (vproj >= 0.) {
+        if (s->nbattr >= 1) {
+            if (depth > 0.)
+                b /= radi, vproj /= radi;
+            else
+                b /= radj, vproj /= radj;
+        }
+        if ((dt_min_b2 >= -0.5 * dt) && (dt_min_b2 < 0.5 * dt))
+            log_event_transit(m->log, (depth > 0.) ? 15 : 16, *s->time + dt_min_b2, *s->id, j, b, vproj);
+        return 1;
+    }
+    return 0;
+}
+
+/* operator(), L108-114; pass_two, L389-402 */
+static void transit_call(monitor *m, double acc[][3], double jerk[][3]) {
+    if (m->p->tr_tol == 0.) return; /* is_any_on() == is_log_on(), L97-99 */
+    int met = 0;
+    for (int b = 1; b < m->s->nbod; b++) met = met || transit_check(m, 0, b, acc, jerk);
+    if (met) log_system(m->log, m->s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* CPU-order force: integrators/hermite_cpu.hpp:74-112                                        */
 static void cpu_calc_forces(const sysref *s, double acc[][3], double jerk[][3]) {
     const int nbod = s->nbod;
@@ -691,8 +765,10 @@ static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor 
     if (mce) mce_init(&s, M); /* hermite_integrator.hpp:99 */
     memcpy(pos, s.pos, sizeof(double) * 3 * nbod);
     memcpy(vel, s.vel, sizeof(double) * 3 * nbod);
-    if (adaptive) mon_call(&mon); /* hermite_adap.hpp:130: monitor runs once before the loop */
+    const int transit = (M->kind == ORC_MON_LOG_TRANSIT);
+    if (adaptive && !transit) mon_call(&mon); /* hermite_adap.hpp:130: monitor runs once before the loop */
     gpu_accjerk(&s, acc0, jerk0);
+    if (adaptive && transit) transit_call(&mon, acc0, jerk0); /* see the note above log_event_transit */
     for (int iter = 0; (iter < P->max_iterations) && *s.state == ORC_ACTIVE; iter++) {
         double h;
         if (adaptive) { /* hermite_adap.hpp:69-98 */
@@ -741,6 +817,8 @@ static void hermite_gpu_system(sysref s, const orc_params *P, const orc_monitor 
         if (accepted) (*accepted)++;
         if (mce)
             mce_call(&mon, c_pos, c_vel); /* L173 */
+        else if (transit)
+            transit_call(&mon, acc1, jerk1);
         else
             mon_call(&mon);
         if (*s.state == ORC_ACTIVE) {

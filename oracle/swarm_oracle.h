@@ -38,7 +38,8 @@ typedef struct {
 
 /* monitor kinds: which reference monitor class the plugin name binds (src/plugins/ *.cu) */
 enum { ORC_MON_EJECTION = 0, ORC_MON_LOG_INTERVAL = 1, ORC_MON_EJECTION_OR_CLOSE = 2,
-       ORC_MON_MCE_STAT = 3 /* monitors/mercury_mce_stat.hpp, bound to `hermite` (plugins/hermite.cu:40) */ };
+       ORC_MON_MCE_STAT = 3, /* monitors/mercury_mce_stat.hpp, bound to `hermite` (plugins/hermite.cu:40) */
+       ORC_MON_LOG_TRANSIT = 4 /* monitors/log_transit.hpp, `hermite_adap_transit` (plugins/hermite_adap.cu:61) */ };
 
 typedef struct {
     int32_t kind;
@@ -53,6 +54,9 @@ typedef struct {
     /* mce_stat_params, src/monitors/mercury_mce_stat.hpp:36-55 (dmin = close_approach, unused) */
     double rceh;          /* rceh= (default 1e-6) */
     double mce_time_step; /* time_step= */
+    /* log_transit_params, src/monitors/log_transit.hpp:42-58 (dt = time_step=) */
+    double tr_tol, tr_dt;
+    int32_t tr_log_transit, tr_log_occultation;
 } orc_monitor;
 
 /* append-only record buffer: the host twin of gpulog::log_base (bits/gpulog_log.h:171-178) */

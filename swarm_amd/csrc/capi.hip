@@ -298,7 +298,7 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     c.ip.error_tolerance = a->error_tolerance;
     c.ip.max_timestep = a->max_timestep;
     c.ip.timestep_scale = a->timestep_scale;
-    if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_MCE_STAT) {
+    if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_LOG_TRANSIT) {
         set_error("unknown monitor id %d", a->monitor);
         return SWARM_HIP_EINVAL;
     }
@@ -319,6 +319,10 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     c.mp.dmin = a->close_approach;
     c.mp.rceh = a->rceh;
     c.mp.mce_time_step = a->time_step; // mce_stat_params reads the same time_step= key (L45)
+    c.mp.tr_tol = a->log_transit_tol;
+    c.mp.tr_dt = a->time_step; // log_transit_params, log_transit.hpp:54
+    c.mp.tr_log_transit = a->log_transits != 0;
+    c.mp.tr_log_occultation = a->log_occultations != 0;
     c.lg.buf = a->log.d_buf;
     c.lg.cursor = a->log.d_cursor;
     c.lg.cap = a->log.capacity;
@@ -373,6 +377,10 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     }
     if (a->monitor == SWARM_HIP_MON_MCE_STAT && a->integrator != SWARM_HIP_HERMITE && a->integrator != SWARM_HIP_IRK2) {
         set_error("monitor mce_stat is bound to the integrators hermite and irk2 only (plugins/hermite.cu:40, irk2.cu:39)");
+        return SWARM_HIP_EINVAL;
+    }
+    if (a->monitor == SWARM_HIP_MON_LOG_TRANSIT && a->integrator != SWARM_HIP_HERMITE_ADAP) {
+        set_error("monitor log_transit is bound to integrator hermite_adap only (plugins/hermite_adap.cu:61)");
         return SWARM_HIP_EINVAL;
     }
     switch (a->integrator) {

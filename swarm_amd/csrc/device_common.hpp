@@ -35,6 +35,9 @@ struct MonParams {
     int ej_verbose, ce_verbose; // verbose_on_*: lprintf records (gpulog MSG_PRINTF)
     double dmin;                // close_approach
     double rceh, mce_time_step; // mce_stat_params (monitors/mercury_mce_stat.hpp:36-55)
+    // log_transit_params (monitors/log_transit.hpp:42-58); dt = the time_step= key
+    double tr_tol, tr_dt;
+    int tr_log_transit, tr_log_occultation;
 };
 
 struct LogBuf {
@@ -532,10 +535,111 @@ __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonPar
         if (__any(want)) log_system(lg, s, want);
 }
 
+// ---------------------------------------------------------------------------------------------
+// log_transit (monitors/log_transit.hpp, plugin hermite_adap_transit, plugins/hermite_adap.cu:61):
+// logs EVT_TRANSIT / EVT_OCCULTATION events (estimated mid-time, impact parameter and sky-projected
+// speed in stellar radii) when a planet passes in front of / behind body 0 as seen along +z, plus a
+// snapshot of the system.  The reference is compiled with USE_WORKS 1 (L32): the estimate is the
+// Taylor extrapolation of calc_transit_time_works (L213-253) from the accelerations and jerks of the
+// integrator's LAST force evaluation, which it reads back from the gravitation object's shared
+// memory -- here the (a, jk) arrays the Hermite step has just produced.  On its first call, before
+// any force evaluation (hermite_adap.hpp:130), the reference reads that shared memory
+// uninitialised; here the first call sees the forces of the initial state.  Marked EXPERIMENTAL in
+// the reference; parity unpinned.
+//
+// log::event(log, evt, T, sys, j, b, vproj) (log/log.hpp:261-265): header | T @8 | sys @16 | j @20 |
+// b @24 | vproj @32, 40 bytes padded to 48.
+__device__ __forceinline__ void log_transit_event(const LogBuf &lg, int evt, double T, int sys, int j, double b,
+                                                  double vproj) {
+    uint8_t *r = log_reserve_lane(lg, 48);
+    if (!r) return;
+    int32_t *ri = reinterpret_cast<int32_t *>(r);
+    double *rd = reinterpret_cast<double *>(r);
+    ri[0] = evt, ri[1] = 48;
+    rd[1] = T;
+    ri[4] = sys, ri[5] = j;
+    rd[3] = b, rd[4] = vproj, rd[5] = 0.0;
+}
+
+// check_in_transit(thread, i = 0, j, dt), L256-386
+template <int N>
+__device__ __forceinline__ bool transit_check(const State<N> &s, const int j, const double (&a)[N][3],
+                                              const double (&jk)[N][3], const double (&radius)[N],
+                                              const bool have_radius, const MonParams &mp, const LogBuf &lg) {
+#pragma clang fp contract(off)
+    const int i = 0;
+    const double dt = mp.tr_dt;
+    const double depth = s.p[j][2] - s.p[i][2];
+    if (!mp.tr_log_occultation && (depth < 0.)) return false;
+    if (!mp.tr_log_transit && (depth > 0.)) return false;
+    double dx[2] = {s.p[j][0] - s.p[i][0], s.p[j][1] - s.p[i][1]};
+    double dv[2] = {s.v[j][0] - s.v[i][0], s.v[j][1] - s.v[i][1]};
+    const double b2begin = dx[0] * dx[0] + dx[1] * dx[1];
+    const double db2dt = 2. * (dx[0] * dv[0] + dx[1] * dv[1]);
+    const double radi = have_radius ? radius[i] : 0.;
+    const double radj = have_radius ? radius[j] : 0.;
+    const double lim = (radi + radj) * (1. + mp.tr_tol);
+    if (fmin(b2begin - 0.5 * dt * db2dt, b2begin + 0.5 * dt * db2dt) > lim * lim) return false;
+    // calc_transit_time_works, L213-253
+    double dt_min_b2, b, vproj;
+    {
+        const double da[2] = {a[j][0] - a[i][0], a[j][1] - a[i][1]};
+        const double dj[2] = {jk[j][0] - jk[i][0], jk[j][1] - jk[i][1]};
+        const double d2b2dt2 = 2. * (dv[0] * dv[0] + dv[1] * dv[1] + dx[0] * da[0] + dx[1] * da[1]);
+        const double d3b2dt3 = 6. * (dv[0] * da[0] + dv[1] * da[1]) + 2. * (dx[0] * dj[0] + dx[1] * dj[1]);
+        double dt_try = -db2dt / d2b2dt2; // vertex of the parabola
+        dt_try = -db2dt / (d2b2dt2 + 0.5 * dt_try * d3b2dt3);
+        if ((dt_try < -0.5 * dt) || (dt_try > 0.5 * dt)) {
+            dt_min_b2 = dt_try, b = -1., vproj = -1.;
+        } else {
+            dt_min_b2 = 0.;
+            double min_b2 = b2begin;
+            dx[0] += dt_try * (dv[0] + dt_try * 0.5 * (da[0] + dt_try * dj[0] / 3.));
+            dx[1] += dt_try * (dv[1] + dt_try * 0.5 * (da[1] + dt_try * dj[1] / 3.));
+            const double b2 = (dx[0] * dx[0] + dx[1] * dx[1]);
+            if (b2 < min_b2) min_b2 = b2, dt_min_b2 = dt_try;
+            b = (min_b2 > 0) ? sqrt(min_b2) : -sqrt(-min_b2);
+            dv[0] += dt_min_b2 * (da[0] + 0.5 * dt_min_b2 * dj[0]);
+            dv[1] += dt_min_b2 * (da[1] + 0.5 * dt_min_b2 * dj[1]);
+            vproj = sqrt(dv[0] * dv[0] + dv[1] * dv[1]);
+        }
+    }
+    if (vproj >= 0.) {
+        if (have_radius) {
+            if (depth > 0.)
+                b /= radi, vproj /= radi;
+            else
+                b /= radj, vproj /= radj;
+        }
+        if ((dt_min_b2 >= -0.5 * dt) && (dt_min_b2 < 0.5 * dt))
+            log_transit_event(lg, (depth > 0.) ? 15 /*EVT_TRANSIT*/ : 16 /*EVT_OCCULTATION*/, s.t + dt_min_b2, s.id, j, b,
+                              vproj);
+        return true;
+    }
+    return false;
+}
+
+// log_transit::operator(), L108-114, 389-402: pass_two ORs check_in_transit over the planets
+// (short-circuit), then the system snapshot when the condition is met
+template <int N>
+__device__ __forceinline__ void transit_monitor(const State<N> &s, const double (&a)[N][3], const double (&jk)[N][3],
+                                                const double (&radius)[N], const bool have_radius,
+                                                const MonParams &mp, const LogBuf &lg) {
+    bool met = false;
+#pragma unroll
+    for (int b = 1; b < N; b++) met = met || transit_check<N>(s, b, a, jk, radius, have_radius, mp, lg);
+    if (met) {
+        uint8_t *r = log_reserve_lane(lg, snapshot_len(N));
+        if (r) snapshot_fill<N>(r, s.t, s.id, s.state, s.p, s.v, s.m);
+    }
+}
+
 // kernel variant for a launch: 0 = monitor has nothing to do, 1 = monitor, 2 = monitor + lprintf
-enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2 };
+//                 3 = mce_stat (kernels_mce.hip, kernels_irk2.hip), 4 = log_transit (hermite_adap_transit)
+enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2, MON_MCE = 3, MON_TRANSIT = 4 };
 __host__ __device__ inline bool monitor_is_noop(const MonParams &mp);
 inline int monitor_variant(const MonParams &mp) {
+    if (mp.kind == SWARM_HIP_MON_LOG_TRANSIT) return mp.tr_tol != 0. ? MON_TRANSIT : MON_OFF; // is_log_on(), L97
     if (monitor_is_noop(mp)) return MON_OFF;
     const bool ej = mp.kind != SWARM_HIP_MON_LOG_INTERVAL && mp.ej_verbose;
     const bool ce = mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && mp.ce_verbose;

@@ -336,6 +336,13 @@ public:
             a.log_on_close_encounter = cfg.optional("log_on_close_encounter", false);
             a.verbose_on_close_encounter = cfg.optional("verbose_on_close_encounter", false);
         }
+        if (MON == SWARM_HIP_MON_LOG_TRANSIT) { // log_transit_params, log_transit.hpp:48-58
+            cfg.require("nbod", 0);
+            a.log_transit_tol = cfg.optional("log_transit_tol", 2.e-8);
+            a.time_step = cfg.require("time_step", 0.0);
+            a.log_transits = cfg.optional("log_transits", true);
+            a.log_occultations = cfg.optional("log_occultations", false);
+        }
         if (MON == SWARM_HIP_MON_LOG_INTERVAL) a.log_interval = cfg.require("log_interval", 0.0); // log_time_interval.hpp:41
         if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_IRK2) a.rceh = cfg.optional("rceh", 1e-6); // mce_stat_params, mercury_mce_stat.hpp:47
         if (ID == SWARM_HIP_IRK2) a.irk2_method = cfg.optional("method", 6); // irk2_integrator.hpp:53
@@ -372,6 +379,7 @@ REG(p_hermite_cpu_log, SWARM_HIP_HERMITE, SWARM_HIP_MON_LOG_INTERVAL, "hermite_c
 REG(p_hermite_adap, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION, "hermite_adap", "Hermite PEC2, adaptive time step (MI355X)");
 REG(p_hermite_adap_log, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_LOG_INTERVAL, "hermite_adap_log", "hermite_adap + log_time_interval");
 REG(p_hermite_adap_ce, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_EJECTION_OR_CLOSE, "hermite_adap_close_encounter", "hermite_adap + stop_on_ejection_or_close_encounter");
+REG(p_hermite_adap_transit, SWARM_HIP_HERMITE_ADAP, SWARM_HIP_MON_LOG_TRANSIT, "hermite_adap_transit", "hermite_adap + log_transit (experimental in the reference)");
 REG(p_rkck_fixed, SWARM_HIP_RKCK_FIXED, SWARM_HIP_MON_EJECTION, "rkck_fixed", "Cash-Karp Runge-Kutta, fixed time step (MI355X)");
 REG(p_rkck_fixed_ce, SWARM_HIP_RKCK_FIXED, SWARM_HIP_MON_EJECTION_OR_CLOSE, "rkck_fixed_close_encounter", "rkck_fixed + stop_on_ejection_or_close_encounter");
 REG(p_rkck_adaptive, SWARM_HIP_RKCK_ADAPTIVE, SWARM_HIP_MON_EJECTION, "rkck_adaptive", "Cash-Karp Runge-Kutta, adaptive time step (MI355X)");
@@ -660,7 +668,17 @@ void execute(const std::string &datafile, time_range_t T, sys_range_t sys, body_
         if (!T.in(r.T()) || !sys.in(r.sys())) continue;
         if (r.msgid() == 1)
             record_output_1(out, r, bod);
-        else { // record_output_default
+        else if (r.msgid() == 15 || r.msgid() == 16) { // record_output_15 / _16, query.cpp:243-294
+            int body_id;
+            double minb, vproj;
+            memcpy(&body_id, r.ptr + 20, 4), memcpy(&minb, r.ptr + 24, 8), memcpy(&vproj, r.ptr + 32, 8);
+            if (bod.in(body_id)) {
+                char buf[1000];
+                snprintf(buf, sizeof(buf), "%10d %lg  %6d %6d  %lg %lg %s Experimental", r.msgid(), r.T(), r.sys(), body_id, minb,
+                         vproj, r.msgid() == 15 ? "Transit" : "Occultation");
+                out << buf;
+            }
+        } else { // record_output_default
             char buf[200];
             snprintf(buf, sizeof(buf), "%10d %lg  %6d", r.msgid(), r.T(), r.sys());
             out << buf;

@@ -19,9 +19,21 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
     const int state_in = s.state;
     MonState ms;
     mon_init(ms, s);
+    double radius[N]; // log_transit: body attribute 0
+    const bool have_radius = e.nbf > 7;
+    if (MON == MON_TRANSIT) {
+#pragma unroll
+        for (int b = 0; b < N; b++)
+            radius[b] = have_radius ? e.body[((size_t)(gid / W) * N + b) * e.nbf * W + (size_t)7 * W + gid % W] : 0.0;
+    }
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop,
     // for every system of the ensemble whatever its state.
-    if (ADAPTIVE && MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
+    if (ADAPTIVE && MON == MON_TRANSIT) {
+        double a0[N][3], j0[N][3];
+        accjerk<N>(s.p, s.v, s.m, a0, j0);
+        transit_monitor<N>(s, a0, j0, radius, have_radius, mp, lg);
+    } else if (ADAPTIVE && MON)
+        mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
 
     unsigned long long steps = 0;
     if (s.state == SWARM_HIP_ACTIVE) {
@@ -37,7 +49,10 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
             hermite_step<N>(s, k, a0, j0, a1, j1);
             s.t += h;
             steps++;
-            if (MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
+            if (MON == MON_TRANSIT)
+                transit_monitor<N>(s, a1, j1, radius, have_radius, mp, lg);
+            else if (MON)
+                mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
             if (s.state == SWARM_HIP_ACTIVE) {
                 // end test: hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
 #pragma clang fp contract(off)
@@ -111,6 +126,14 @@ static int launch_n(const LaunchCtx &c) {
     switch (monitor_variant(c.mp)) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
     case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    case MON_TRANSIT:
+        if constexpr (ADAPTIVE) { // plugins/hermite_adap.cu:61 is the only registration of log_transit
+            SWH_LAUNCH_VARIANT(MON_TRANSIT);
+        } else {
+            set_error("monitor log_transit is bound to hermite_adap only (plugins/hermite_adap.cu:61)");
+            return SWARM_HIP_EINVAL;
+        }
+        break;
     default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
     }
 #undef SWH_LAUNCH_VARIANT

@@ -45,8 +45,7 @@ struct IrkCoef {
     }
 };
 
-// MON: MON_OFF / MON_ON (stop_on_ejection family, lprintf-capable) / 3 = mce_stat
-constexpr int MON_MCE = 3;
+// MON: MON_OFF / MON_ON (stop_on_ejection family, lprintf-capable) / MON_MCE
 
 template <int N, int NS, int MON>
 __global__ __launch_bounds__(256) void irk2_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt,

@@ -41,6 +41,7 @@ PLUGINS = {
     "integrator_hermite_adap": (capi.HERMITE_ADAP, capi.MON_EJECTION),
     "integrator_hermite_adap_log": (capi.HERMITE_ADAP, capi.MON_LOG_INTERVAL),
     "integrator_hermite_adap_close_encounter": (capi.HERMITE_ADAP, capi.MON_EJECTION_OR_CLOSE),
+    "integrator_hermite_adap_transit": (capi.HERMITE_ADAP, capi.MON_LOG_TRANSIT),      # plugins/hermite_adap.cu:61
     "integrator_rkck_fixed": (capi.RKCK_FIXED, capi.MON_EJECTION),
     "integrator_rkck_fixed_close_encounter": (capi.RKCK_FIXED, capi.MON_EJECTION_OR_CLOSE),
     "integrator_rkck_adaptive": (capi.RKCK_ADAPTIVE, capi.MON_EJECTION),
@@ -210,6 +211,12 @@ class GpuIntegrator(Integrator):
             a.verbose_on_close_encounter = int(cfg.optional("verbose_on_close_encounter", False))
         if self.mon_id == capi.MON_LOG_INTERVAL:                      # log_time_interval.hpp:39-43
             a.log_interval = cfg.require("log_interval", 0.0)
+        if self.mon_id == capi.MON_LOG_TRANSIT:                       # log_transit_params, log_transit.hpp:48-58
+            cfg.require("nbod", 0)
+            a.log_transit_tol = cfg.optional("log_transit_tol", 2.e-8)
+            a.time_step = cfg.require("time_step", 0.0)               # "use hermite's timestep"
+            a.log_transits = int(cfg.optional("log_transits", True))
+            a.log_occultations = int(cfg.optional("log_occultations", False))
         if self.name in ("hermite", "irk2"):                          # mce_stat_params, mercury_mce_stat.hpp:42-53
             a.rceh = cfg.optional("rceh", 1e-6)
         if self.int_id == capi.IRK2:                                  # irk2_integrator.hpp:53

@@ -278,3 +278,21 @@ def test_reference_irk2_cpu_cfg_one_million_steps():
             os.path.join(INTEG, "test.3.out.txt"), "nbod=3", "destination_time=1", "pos_threshold=1E-8",
             "vel_threshold=1E-8", "-v", "1")
     assert "Test success" in p.stderr
+
+
+@pytest.mark.gpu
+def test_transit_events_in_the_binary_log_and_query(tmp_path, oracle):
+    """hermite_adap_transit -> binary writer -> `swarm query`: EVT_TRANSIT lines in the format of
+    record_output_15 (swarm/query.cpp:243-257)"""
+    from test_gpu_monitors import edge_on
+    O = oracle
+    e = edge_on(O, 16)
+    inp, log = tmp_path / "in.txt", tmp_path / "tr.bin"
+    O.save_text(e, str(inp))
+    run("integrate", "-I", inp, "integrator=hermite_adap_transit", "time_step_factor=0.017", "min_time_step=1e-5", "nbod=3",
+        "time_step=0.01", "destination_time=8", "log_writer=binary", "log_output=%s" % log)
+    p = run("query", "-f", log)
+    lines = [l for l in p.stdout.splitlines() if l.endswith("Transit Experimental")]
+    assert len(lines) >= 16 and all(l.split()[0] == "15" for l in lines)
+    t, sysid, bod, b, v = lines[0].split()[1:6]
+    assert 0 < float(t) < 8 and int(bod) in (1, 2) and abs(float(b)) < 1.2 and float(v) > 1

@@ -142,3 +142,50 @@ def test_close_encounter_composite(gpu, oracle):
     assert 20 < (o.state == O.DISABLED).sum() < 100
     assert (h.state == o.state).all()
     np.testing.assert_allclose(h.time, o.time, rtol=1e-9)
+
+
+def edge_on(O, n=64):
+    """orbits tilted by <= 0.05 rad from the line of sight (+z): planets transit and are occulted by the star"""
+    e = O.Ensemble(n, 3, 1, 1)
+    g = O.generate(n, 3, planet_mass=1e-4)
+    for k in ("mass", "time", "state", "id"):
+        setattr(e, k, getattr(g, k).copy())
+    e.body_attr[:, 0, 0], e.body_attr[:, 1:, 0] = 0.1, 0.01
+    for j, r in ((1, 1.0), (2, 1.6)):
+        ph = np.linspace(0, 2 * np.pi, n, endpoint=False) + 0.3 * j
+        v, inc = np.sqrt(1 / r), np.linspace(0, 0.05, n)
+        e.pos[:, j] = np.stack([r * np.cos(ph), r * np.sin(ph) * np.sin(inc), r * np.sin(ph) * np.cos(inc)], -1)
+        e.vel[:, j] = np.stack([-v * np.sin(ph), v * np.cos(ph) * np.sin(inc), v * np.cos(ph) * np.cos(inc)], -1)
+    return e
+
+
+def test_log_transit_events(gpu, oracle):
+    """hermite_adap_transit (plugins/hermite_adap.cu:61, monitors/log_transit.hpp): EVT_TRANSIT / EVT_OCCULTATION
+    events + a snapshot per event.  Same events as the oracle's restatement: (system, body, kind) sequence
+    identical, mid-times to 1e-10, impact parameter and projected speed (in stellar / planetary radii) to 1e-7.
+    PARITY UNPINNED (experimental monitor, no fixture in the reference)."""
+    S, O = gpu, oracle
+    e = edge_on(O)
+    h = to_host(S, e)
+    cfg = {"integrator": "hermite_adap_transit", "time_step_factor": "0.017", "min_time_step": "1e-5", "nbod": "3",
+           "time_step": "0.01", "log_occultations": "1"}
+    integ, lm = make(S, cfg, h, 15.0, log_bytes=8 << 20)
+    olog = O.Log(8 << 20)
+    O.integrate(e, O.params("hermite_adap", 15.0, time_step_factor=0.017, min_time_step=1e-5),
+                O.monitor(kind=O.MON_LOG_TRANSIT, transit_dt=0.01, log_occultations=1), olog)
+    g = sorted((r for r in O.parse_log(bytes(lm.host)) if r["msgid"] in (15, 16)), key=lambda r: (r["sys"], r["time"]))
+    o = sorted((r for r in olog.records() if r["msgid"] in (15, 16)), key=lambda r: (r["sys"], r["time"]))
+    assert len(g) == len(o) > 300
+    assert [(r["sys"], r["body"], r["msgid"]) for r in g] == [(r["sys"], r["body"], r["msgid"]) for r in o]
+    np.testing.assert_allclose([r["time"] for r in g], [r["time"] for r in o], rtol=1e-10)
+    np.testing.assert_allclose([r["b"] for r in g], [r["b"] for r in o], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose([r["vproj"] for r in g], [r["vproj"] for r in o], rtol=1e-8)
+    nsnap = sum(1 for r in O.parse_log(bytes(lm.host)) if r["msgid"] == 1)
+    assert nsnap == sum(1 for r in olog.records() if r["msgid"] == 1)
+    # transits only (the default): no EVT_OCCULTATION
+    h2 = to_host(S, edge_on(O))
+    del cfg["log_occultations"]
+    _, lm2 = make(S, cfg, h2, 15.0, log_bytes=8 << 20)
+    kinds = {r["msgid"] for r in O.parse_log(bytes(lm2.host))}
+    assert kinds == {1, 15}
+    assert (h2.pos == h.pos).all()                       # the monitor never touches the trajectory
