@@ -81,11 +81,13 @@ typedef struct swarm_hip_ensemble {
 /* Device event buffer: replaces gpulog::log_base {char* buffer; int* at; int buf_len}
  * (swarm/log/gpulog/bits/gpulog_log.h:171-178).  Records are byte-compatible with the
  * reference (EVT_SNAPSHOT layout: log/log.hpp:313-326, log/types.hpp:37-56).
- * d_cursor[0] = bytes used, d_cursor[1] = records dropped because the buffer was full
+ * d_cursor[0] = bytes used, d_cursor[2] = lprintf (MSG_PRINTF) records among them (so that a flush
+ * only walks the buffer for replay_printf when there is something to print), d_cursor[3] reserved,
+ * d_cursor[1] = records dropped because the buffer was full
  * (the reference drops them silently, bits/gpulog_write.h:14-22). */
 typedef struct swarm_hip_log {
     uint8_t *d_buf;
-    int32_t *d_cursor; /* int32[2] */
+    int32_t *d_cursor; /* int32[4], zeroed by the caller */
     int32_t capacity;  /* bytes */
 } swarm_hip_log_t;
 

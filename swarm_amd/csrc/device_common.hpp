@@ -42,7 +42,7 @@ struct MonParams {
 
 struct LogBuf {
     uint8_t *buf;
-    int32_t *cursor; // [0] bytes used, [1] dropped records
+    int32_t *cursor; // [0] bytes used, [1] dropped records, [2] lprintf records written, [3] reserved
     int32_t cap;
 };
 
@@ -381,6 +381,7 @@ static __device__ __noinline__ void log_printf_lane(const LogBuf &lg, const char
     const int len = (at + 15) / 16 * 16;
     uint8_t *r = log_reserve_lane(lg, len);
     if (!r) return;
+    atomicAdd(lg.cursor + 2, 1);
     for (int k = 8; k < len; k += 4) *reinterpret_cast<int32_t *>(r + k) = 0;
     reinterpret_cast<int32_t *>(r)[0] = -2; // MSG_PRINTF
     reinterpret_cast<int32_t *>(r)[1] = len;

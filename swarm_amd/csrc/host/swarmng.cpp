@@ -92,9 +92,9 @@ void manager::init(const config &cfg, int, int device_buffer_size) {
     if (dynamic_cast<null_writer *>(log_writer.get())) return; // null sink: no device buffer
     capacity = device_buffer_size;
     hipErrCheck(swarm_hip_malloc((void **)&d_buf, (size_t)capacity));
-    hipErrCheck(swarm_hip_malloc((void **)&d_cursor, 8));
+    hipErrCheck(swarm_hip_malloc((void **)&d_cursor, 16));
     hipErrCheck(swarm_hip_host_alloc((void **)&host, (size_t)capacity));
-    hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));
+    hipErrCheck(swarm_hip_memset(d_cursor, 0, 16, 0));
     hipErrCheck(swarm_hip_synchronize(0));
 }
 Pmanager &manager::default_log() {
@@ -171,16 +171,16 @@ int replay_printf(std::ostream &out, const char *p, size_t n) {
 
 void manager::flush() {
     if (!d_buf) return;
-    int32_t cur[2] = {0, 0};
-    hipErrCheck(swarm_hip_memcpy_d2h(cur, d_cursor, 8));
+    int32_t cur[4] = {0, 0, 0, 0}; // bytes used, dropped, lprintf records, -
+    hipErrCheck(swarm_hip_memcpy_d2h(cur, d_cursor, 16));
     _dropped += cur[1];
     if (cur[0] > 0) {
         hipErrCheck(swarm_hip_memcpy_d2h(host, d_buf, (size_t)cur[0]));
-        replay_printf(std::cerr, (const char *)host, (size_t)cur[0]); // logmanager.cpp:83
+        if (cur[2]) replay_printf(std::cerr, (const char *)host, (size_t)cur[0]); // logmanager.cpp:83
         log_writer->process((const char *)host, (size_t)cur[0]);
     }
     if (cur[0] || cur[1]) {
-        hipErrCheck(swarm_hip_memset(d_cursor, 0, 8, 0));
+        hipErrCheck(swarm_hip_memset(d_cursor, 0, 16, 0));
         hipErrCheck(swarm_hip_synchronize(0));
     }
 }

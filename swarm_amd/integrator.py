@@ -67,7 +67,7 @@ class LogManager:
         self.capacity = int(device_bytes)
         self.writer = writer  # callable(bytes) or None (= null writer)
         self.buf = DeviceBuffer(self.capacity) if self.capacity else None
-        self.cursor = DeviceBuffer(8) if self.capacity else None
+        self.cursor = DeviceBuffer(16) if self.capacity else None   # int32[4]: used, dropped, lprintf records, -
         if self.cursor:
             self.cursor.zero()
         self.host = bytearray()
@@ -109,13 +109,13 @@ class LogManager:
         if not self.capacity:
             return
         cur = self.cursor.to_host(np.int32)
-        used, dropped = int(cur[0]), int(cur[1])
+        used, dropped, nprintf = int(cur[0]), int(cur[1]), int(cur[2])
         self.dropped += dropped
         if used:
             capi.check(capi.lib.swarm_hip_memcpy_d2h(self._pinned, self.buf.ptr, used))
             self.bytes_flushed += used
-            if self.replay_printf and used:   # logmanager.cpp:83: replay_printf(std::cerr, hlog)
-                self._replay(used)
+            if self.replay_printf and nprintf:   # logmanager.cpp:83: replay_printf(std::cerr, hlog)
+                self.printf_count += gpulog.replay_printf(sys.stderr, self._stage[:used].tobytes())
             if self.writer == "host":
                 self.host += memoryview(self._stage[:used])
             elif self.writer == "count":
@@ -125,23 +125,6 @@ class LogManager:
         if used or dropped:
             self.cursor.zero()
 
-
-    def _replay(self, used):
-        view = self._stage[:used]
-        # cheap pre-scan of the headers: only buffers that hold a printf record are formatted
-        off = 0
-        hdr = view.view(np.int32) if used % 4 == 0 else None
-        found = False
-        while hdr is not None and off < used:
-            if hdr[off // 4] == gpulog.MSG_PRINTF:
-                found = True
-                break
-            ln = int(hdr[off // 4 + 1])
-            if ln <= 0:
-                break
-            off += ln
-        if found:
-            self.printf_count += gpulog.replay_printf(sys.stderr, view[off:].tobytes())
 
 
 class Integrator:
