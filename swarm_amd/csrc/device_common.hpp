@@ -214,10 +214,13 @@ struct StepConsts {
     double h, hh, h3;        // h, h*0.5, h/3.0             (predictor, hermite_integrator.hpp:131-132)
     double kp_a, kp_j0, kp_j1; // position corrector weights  (L146)
     double kv_a, kv_j0, kv_j1; // velocity corrector weights  (L147)
+    // FAST: h/3 through the 1-ulp reciprocal path (adaptive steps recompute the constants every step and
+    // an IEEE divide costs ~60 cycles there); the fixed-step kernels keep the IEEE quotient
+    template <bool FAST = false>
     __device__ __forceinline__ void set(double h_) {
         h = h_;
         hh = h_ * 0.5;
-        h3 = h_ / 3.0;
+        h3 = FAST ? h_ * (1.0 / 3.0) : h_ / 3.0;
         const double h2 = h_ * h_;
         const double c60 = (1.0 / 60.0) * h_, c12 = (1.0 / 12.0) * h_;
         // pos = pre + ((0.1-0.25)*(a0-a1) - 1/60*(7 j0 + 2 j1) h) h^2, expanded per operand

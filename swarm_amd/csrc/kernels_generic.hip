@@ -126,19 +126,23 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
     const double N_LAG = 5.0;
     const double smu = sqrtGM;
     const double GM = sqrtGM * sqrtGM;
-    double r0[G], alpha[G], sig0[G], foo[G], x[G], u[G];
+    // a / b is a * rcp_full(b) throughout (fdiv): the reciprocals of the launch constants and of r0 are
+    // formed once and shared, which leaves the products unchanged
+    const double inv_smu = rcp_full(smu), inv_GM = rcp_full(GM);
+    double r0[G], inv_r0[G], alpha[G], sig0[G], foo[G], x[G], u[G];
     bool live[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const double(&p)[3] = s.p[B0 + g];
         const double(&v)[3] = s.v[B0 + g];
         r0[g] = fsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        inv_r0[g] = rcp_full(r0[g]);
         const double v2 = (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         const double r0dotv0 = (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]);
-        alpha[g] = (fdiv(2.0, r0[g]) - fdiv(v2, GM));
+        alpha[g] = (2.0 * inv_r0[g] - v2 * inv_GM);
         foo[g] = 1.0 - r0[g] * alpha[g];
-        sig0[g] = fdiv(r0dotv0, smu);
-        x[g] = fdiv(sqrtGM * sqrtGM * deltaTime * deltaTime, r0[g]);
+        sig0[g] = r0dotv0 * inv_smu;
+        x[g] = (sqrtGM * sqrtGM * deltaTime * deltaTime) * inv_r0[g];
         u[g] = 1.0;
         live[g] = true;
     }
@@ -181,8 +185,8 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
         const double x_p = x[g], x2 = x_p * x_p, x3 = x2 * x_p;
         double r = sig0[g] * x_p * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
         if (r < 0.) r = 0.;
-        const double f_p = 1.0 - fdiv(x2, r0[g]) * Cp[g];
-        const double g_p = deltaTime - fdiv(x3, smu) * Sp[g];
+        const double f_p = 1.0 - (x2 * inv_r0[g]) * Cp[g];
+        const double g_p = deltaTime - (x3 * inv_smu) * Sp[g];
         const double dgdt = 1.0 - fdiv(x2, r) * Cp[g];
         double dfdt;
         if (fabs(g_p) > 1e-8)
@@ -261,8 +265,10 @@ __device__ __forceinline__ void mvs_to_std(State<N> &s) {
     }
 }
 // MVSPropagator::drift_step, mvs.hpp:242-256
+// (`/ m0` is a multiplication by the launch-constant 1/m0: 1 ulp from the reference's quotient, 6 IEEE
+// divides per step less)
 template <int N>
-__device__ __forceinline__ void mvs_drift(State<N> &s, double hby2) {
+__device__ __forceinline__ void mvs_drift(State<N> &s, double hby2, double inv_m0) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         double mv = 0;
@@ -270,7 +276,7 @@ __device__ __forceinline__ void mvs_drift(State<N> &s, double hby2) {
         for (int j = 1; j < N; ++j) mv += s.m[j] * s.v[j][c];
         s.p[0][c] += hby2 * s.v[0][c];
 #pragma unroll
-        for (int b = 1; b < N; b++) s.p[b][c] += mv * hby2 / s.m[0];
+        for (int b = 1; b < N; b++) s.p[b][c] += mv * hby2 * inv_m0;
     }
 }
 
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
         mon_init(ms, s);
         double acc[N][3];
         double sqrtGM = 0., timestep = 0.;
+        const double inv_m0 = 1.0 / s.m[0];
         // prop.init()
         if (KIND == SWARM_HIP_MVS) {
             sqrtGM = sqrt(s.m[0]);
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
             }
             if (KIND == SWARM_HIP_MVS) { // MVSPropagator::advance, mvs.hpp:260-293
                 const double hby2 = 0.5 * fmin(max_timestep, ip.time_step);
-                mvs_drift(s, hby2);
+                mvs_drift(s, hby2, inv_m0);
 #pragma unroll
                 for (int b = 1; b < N; b++)
 #pragma unroll
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, M
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
-                mvs_drift(s, hby2);
+                mvs_drift(s, hby2, inv_m0);
                 s.t += 2.0 * hby2;
             } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
                 const double h = fmin(ip.time_step, max_timestep);

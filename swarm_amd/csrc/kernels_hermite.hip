@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
                 for (int b = 0; b < N; b++) {
                     const double a2 = fa[0][b][0] * fa[0][b][0] + fa[0][b][1] * fa[0][b][1] + fa[0][b][2] * fa[0][b][2];
                     const double jj = fj[0][b][0] * fj[0][b][0] + fj[0][b][1] * fj[0][b][1] + fj[0][b][2] * fj[0][b][2];
-                    const double ratio = jj / a2;
+                    const double ratio = fdiv(jj, a2);
                     tf = (b == 0) ? ratio : tf + ratio;
                 }
                 h = rsqrt_full(tf) * ip.time_step_factor + ip.min_time_step;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
                 if (s.t + h > dest) h = dest - s.t;
             }
-            k.set(h);
+            k.template set<ADAPTIVE>(h);
             finish_step(h, fa[0], fj[0], fa[1], fj[1]);
             iter++;
 #pragma unroll
