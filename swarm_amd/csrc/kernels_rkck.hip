@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
                 }
             }
             if (ADAPTIVE) {
-                const double pen = pem / pm, ven = vem / vm; // L232-238
+                // L232-238; quotients through the 1-ulp reciprocal path: the estimate itself is a difference of
+                // nearly equal sums and is good to a few digits only
+                const double pen = fdiv(pem, pm), ven = fdiv(vem, vm);
                 max_error = fmax(fmax(pen, ven), max_error);
             }
         }
