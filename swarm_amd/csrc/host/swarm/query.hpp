@@ -56,6 +56,11 @@ typedef range<double> time_range_t;
 
 enum planets_coordinate_system_t { astrocentric, barycentric, jacobi, origin };
 void set_coordinate_system(const planets_coordinate_system_t &c);
+void set_keplerian_output(); // query.cpp:67-69, `swarm query -k`
+// Cartesian state relative to the centre -> (a, e, i, O, w, M), angles in radians; the conventions and
+// the case split (parabola / ellipse / hyperbola, TINY = 1e-8) of tutorials/kepler.cpp:102-200
+void calc_keplerian_for_cartesian(double &a, double &e, double &i, double &O, double &w, double &M, double x, double y,
+                                  double z, double vx, double vy, double vz, double GM);
 
 // io.cpp:226-264: read <infn> (unsorted), sort records by (T, sys, position), write <outfn>
 bool sort_binary_log_file(const std::string &outfn, const std::string &infn);

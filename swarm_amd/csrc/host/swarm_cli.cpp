@@ -389,7 +389,6 @@ static int real_main(int argc, char *argv[]) {
     } else if (command == "query") { // swarm.cpp:602-646
         using namespace query;
         if (!argvars.count("logfile")) { cerr << "Name of input log file is missing \n"; return 1; }
-        if (argvars.count("keplerian")) ERROR("Keplerian output is not supported by this build");
         time_range_t T;
         sys_range_t sys, body_range;
         if (argvars.count("time")) T = time_range_t::parse(argvars["time"]);
@@ -400,7 +399,11 @@ static int real_main(int argc, char *argv[]) {
         if (argvars.count("barycentric")) query::set_coordinate_system(query::barycentric);
         if (argvars.count("jacobi")) query::set_coordinate_system(query::jacobi);
         std::cout.flush();
-        std::cerr << "# Output in Cartesian coordinates  \n";
+        if (argvars.count("keplerian")) {
+            query::set_keplerian_output();
+            std::cerr << "# Output in Keplerian coordinates  \n";
+        } else
+            std::cerr << "# Output in Cartesian coordinates  \n";
         query::execute(argvars["logfile"], T, sys, body_range);
     } else if (command == "generate") {
         INFO_OUTPUT(1, "Generating new ensemble:  " << cfg["nsys"] << ", " << cfg["nbod"] << endl);

@@ -535,6 +535,88 @@ const char *SORTED_HEADER_CHECK = "T_sorted_output";
 
 static planets_coordinate_system_t planets_coordinate_system = jacobi; // query.cpp:65
 void set_coordinate_system(const planets_coordinate_system_t &c) { planets_coordinate_system = c; }
+static bool keplerian_output = false;
+void set_keplerian_output() { keplerian_output = true; }
+
+void calc_keplerian_for_cartesian(double &a, double &e, double &i, double &O, double &w, double &M, const double x,
+                                  const double y, const double z, const double vx, const double vy, const double vz,
+                                  const double GM) {
+    const double TINY = 1.e-8, TWOPI = 2. * M_PI;
+    // orbital plane from the angular momentum; u = argument of latitude
+    const double h[3] = {y * vz - z * vy, z * vx - x * vz, x * vy - y * vx};
+    const double h2 = h[0] * h[0] + h[1] * h[1] + h[2] * h[2], hh = sqrt(h2);
+    i = acos(h[2] / hh);
+    double fac = sqrt(h[0] * h[0] + h[1] * h[1]) / hh, u;
+    if (fac < TINY) { // orbit in the reference plane: the node is undefined
+        O = 0.;
+        u = atan2(y, x);
+        if (fabs(i - M_PI) < 10. * TINY) u = -u;
+    } else {
+        O = atan2(h[0], -h[1]);
+        u = atan2(z / sin(i), x * cos(O) + y * sin(O));
+    }
+    if (O < 0.) O += TWOPI;
+    if (u < 0.) u += TWOPI;
+    const double r = sqrt(x * x + y * y + z * z), rdotv = vx * x + vy * y + vz * z;
+    const double energy = (vx * vx + vy * vy + vz * vz) * 0.5 - GM / r;
+    auto wrap = [&](double ang) { // kepler.cpp:141-142
+        if (ang < 0.) ang += TWOPI;
+        return ang - round(ang / TWOPI) * TWOPI;
+    };
+    if (fabs(energy * r / GM) < sqrt(TINY)) { // parabola (kepler.cpp:131-143; its `w` is read before it is set: 0 here)
+        a = 0.5 * h2 / GM;
+        e = 1.;
+        const double ww = acos(2. * a / r - 1.);
+        w = 0.;
+        if (rdotv < 0.) w = TWOPI - w;
+        const double tmpf = tan(0.5 * w);
+        M = tmpf * (1. + tmpf * tmpf / 3.);
+        w = wrap(u - ww);
+    } else if (energy < 0) { // ellipse
+        a = -0.5 * GM / energy;
+        fac = 1. - h2 / (GM * a);
+        double ww, cape;
+        if (fac > TINY) {
+            e = sqrt(fac);
+            const double face = (a - r) / (a * e);
+            cape = face > 1. ? 0. : (face > -1. ? acos(face) : M_PI);
+            if (rdotv < 0.) cape = TWOPI - cape;
+            const double cw = (cos(cape) - e) / (1. - e * cos(cape));
+            const double sw = sqrt(1. - e * e) * sin(cape) / (1. - e * cos(cape));
+            ww = atan2(sw, cw);
+            if (ww < 0.) ww += TWOPI;
+        } else {
+            e = 0.;
+            ww = u;
+            cape = u;
+        }
+        M = cape - e * sin(cape);
+        w = wrap(u - ww);
+    } else { // hyperbola (energy > 0; energy == 0 is caught by the parabola test)
+        a = 0.5 * GM / energy;
+        fac = h2 / (GM * a);
+        double ww, capf;
+        if (fac > TINY) {
+            e = sqrt(1. + fac);
+            const double tmpf = (a + r) / (a * e);
+            capf = std::log(tmpf + sqrt(tmpf * tmpf - 1.));
+            if (rdotv < 0.) capf = -capf;
+            const double cw = (e - cosh(capf)) / (e * cosh(capf) - 1.);
+            const double sw = sqrt(e * e - 1.) * sinh(capf) / (e * cosh(capf) - 1.);
+            ww = atan2(sw, cw);
+            if (ww < 0.) ww += TWOPI;
+        } else {
+            e = 1.;
+            double tmpf = 0.5 * h2 / GM;
+            ww = acos(2. * tmpf / r - 1.);
+            if (rdotv < 0.) ww = TWOPI - ww;
+            tmpf = (a + r) / (a * e);
+            capf = std::log(tmpf + sqrt(tmpf * tmpf - 1.));
+        }
+        M = e * sinh(capf) - capf;
+        w = wrap(u - ww);
+    }
+}
 
 template <typename T> static T arg_parse(const std::string &s) {
     if (s == "MIN") return range<T>().first;
@@ -650,9 +732,21 @@ static void record_output_1(std::ostream &out, const rec_t &r, const body_range_
         if (planets_coordinate_system == jacobi) center = center_of_mass(bodies.data(), bod);
         double x = b.x - center.x, y = b.y - center.y, z = b.z - center.z;
         double vx = b.vx - center.vx, vy = b.vy - center.vy, vz = b.vz - center.vz;
-        snprintf(buf, sizeof(buf), "%10d %lg  %6d %6d  %lg  %9.5lg %9.5lg %9.5lg  %9.5lg %9.5lg %9.5lg  %d", r.msgid(), time,
-                 sys, bod, b.mass, x, y, z, vx, vy, vz, flags);
-        out << buf;
+        if (keplerian_output && bod > 0) { // query.cpp:187-194
+            double cm = center.mass;
+            if (planets_coordinate_system == barycentric) cm -= b.mass;
+            double ka, ke, ki, kO, kw, kM;
+            calc_keplerian_for_cartesian(ka, ke, ki, kO, kw, kM, x, y, z, vx, vy, vz, b.mass + cm);
+            const double rad2deg = 180. / M_PI;
+            snprintf(buf, sizeof(buf), "%10d %lg  %6d %6d  %lg  % 9.5lg % 9.5lg % 9.5lg  % 9.5lg % 9.5lg % 9.5lg  %d", r.msgid(),
+                     time, sys, bod, b.mass, ka, ke, ki * rad2deg, kO * rad2deg, kw * rad2deg, kM * rad2deg, flags);
+            out << buf;
+        }
+        if (!keplerian_output) {
+            snprintf(buf, sizeof(buf), "%10d %lg  %6d %6d  %lg  %9.5lg %9.5lg %9.5lg  %9.5lg %9.5lg %9.5lg  %d", r.msgid(), time,
+                     sys, bod, b.mass, x, y, z, vx, vy, vz, flags);
+            out << buf;
+        }
     }
 }
 
@@ -791,3 +885,9 @@ bool compare_ensembles(ensemble &e1, ensemble &e2, double &pos_diff, double &vel
 }
 
 } // namespace swarm
+
+// C entry for the Python API (swarm_amd/swarmng.py: calc_keplerian_for_cartesian, module.cpp:65-73)
+extern "C" void swarmng_calc_keplerian_for_cartesian(double *out6, double x, double y, double z, double vx, double vy,
+                                                     double vz, double GM) {
+    swarm::query::calc_keplerian_for_cartesian(out6[0], out6[1], out6[2], out6[3], out6[4], out6[5], x, y, z, vx, vy, vz, GM);
+}

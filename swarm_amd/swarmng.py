@@ -214,6 +214,19 @@ class GpuIntegrator(Integrator):
         self._impl.set_log_manager(lm)
 
 
+def calc_keplerian_for_cartesian(x, y, z, vx, vy, vz, GM):
+    """swarmng.calc_keplerian_for_cartesian (src/python/module.cpp:65-73,186): -> [a, e, i, O, w, M], angles in
+    radians; conventions of tutorials/kepler.cpp:102-200 (through libswarmng_hip.so)"""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libswarmng_hip.so"))
+    f = lib.swarmng_calc_keplerian_for_cartesian
+    f.argtypes = [C.POINTER(C.c_double)] + [C.c_double] * 7
+    out = (C.c_double * 6)()
+    f(out, x, y, z, vx, vy, vz, GM)
+    return list(out)
+
+
 def find_max_energy_conservation_error(ens, reference_ensemble):
     """swarm/utils.cpp:105-121"""
     e0, e1 = reference_ensemble.calc_total_energy(), ens.calc_total_energy()

@@ -97,6 +97,15 @@ def test_query_reproduces_reference_bdb_golden(tmp_path, oracle):
     assert [int(r[3]) for r in rows] == [0, 1, 2, 3] and [float(x) for x in rows[0][5:11]] == [0.0] * 6
     p = run("query", check=False)
     assert p.returncode == 1 and "Name of input log file is missing" in p.stderr
+    # -k: Keplerian elements (query.cpp:187-194, tutorials/kepler.cpp:102-200).  The fixture's planets are on
+    # circular, coplanar orbits of radius 1, 1.4, 1.96 about a unit-mass star (Jacobi centre of mass).
+    p = run("query", "-f", raw, "-k", "-t", "MIN..0.05")
+    assert "# Output in Keplerian coordinates" in p.stderr
+    rows = [l.split() for l in p.stdout.splitlines() if l.strip()]
+    assert len(rows) == 16 * 3
+    for r in rows:
+        a, e, inc = float(r[5]), float(r[6]), float(r[7])
+        assert abs(a - 1.4 ** (int(r[3]) - 1)) < 0.02 and e < 0.02 and inc == 0.0
 
 
 # ---------------------------------------------------------------- GPU side

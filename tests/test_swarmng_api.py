@@ -64,6 +64,21 @@ def test_api_surface_without_gpu(tmp_path):
     assert e[0].total_energy == pytest.approx(e.calc_total_energy()[0])
 
 
+def test_calc_keplerian_for_cartesian():
+    """module.cpp:186; elements of known orbits (tutorials/kepler.cpp:102-200 conventions)"""
+    import swarm_amd.swarmng as swarmng
+    a, e, i, O, w, M = swarmng.calc_keplerian_for_cartesian(10.0, 0, 0, 0, math.sqrt(1.0 / 10.0), 0, 1.0)
+    assert a == pytest.approx(10.0) and e == 0.0 and i == 0.0 and O == 0.0
+    # ellipse a=2, e=0.5 at pericentre (r=1, v^2 = GM(2/r - 1/a) = 1.5), inclined by 30 degrees about the x axis
+    v = math.sqrt(1.5)
+    a, e, i, O, w, M = swarmng.calc_keplerian_for_cartesian(1.0, 0, 0, 0, v * math.cos(math.pi / 6), v * math.sin(math.pi / 6), 1.0)
+    assert a == pytest.approx(2.0) and e == pytest.approx(0.5) and i == pytest.approx(math.pi / 6)
+    assert M == pytest.approx(0.0, abs=1e-7) and O == pytest.approx(0.0, abs=1e-12) and w == pytest.approx(0.0, abs=1e-7)
+    # hyperbola: v^2 = 2/r + 1/a with a = 1 -> e = 1 + r_p/a = 2 at pericentre r_p = 1
+    a, e, i, O, w, M = swarmng.calc_keplerian_for_cartesian(1.0, 0, 0, 0, math.sqrt(3.0), 0, 1.0)
+    assert a == pytest.approx(1.0) and e == pytest.approx(2.0) and M == pytest.approx(0.0, abs=1e-7)
+
+
 def test_snapshot_files_interoperate_with_cli_and_reference_fixtures(tmp_path, oracle):
     """python text/binary I/O reads the reference's fixture and the C++ CLI's binary output"""
     import os
