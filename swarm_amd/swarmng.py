@@ -227,6 +227,43 @@ def calc_keplerian_for_cartesian(x, y, z, vx, vy, vz, GM):
     return list(out)
 
 
+def calc_cartesian_for_keplerian(a, e, i, O, w, M, GM=1.0):
+    """swarmng.calc_cartesian_for_keplerian (module.cpp:79-91,187) = calc_cartesian_for_ellipse
+    (tutorials/kepler.cpp:30-101): elliptic elements -> [x, y, z, vx, vy, vz].  Kepler's equation by the
+    cube-root start and three third-order corrections of Mercury's orbel_ehie, as there.  The reference's
+    wrapper hands an uninitialised GM to the C++ routine; here GM is an argument (default 1)."""
+    import math
+
+    def improve(e, M, x):
+        sx, cx = math.sin(x), math.cos(x)
+        es, ec = e * sx, e * cx
+        f, fp, fpp, fppp = x - es - M, 1. - ec, es, ec
+        dx = -f / fp
+        dx = -f / (fp + dx * fpp / 2.)
+        dx = -f / (fp + dx * fpp / 2. + dx * dx * fppp / 6.)
+        return x + dx
+
+    M = M - int(M / (2. * math.pi)) * 2. * math.pi
+    if M < 0.:
+        M += 2. * math.pi
+    flip = M > math.pi
+    if flip:
+        M = 2. * math.pi - M
+    x = (6. * M) ** (1. / 3.)
+    for _ in range(3):
+        x = improve(e, M, x)
+    cape = 2. * math.pi - x if flip else x
+    scap, ccap = math.sin(cape), math.cos(cape)
+    sqe, sqgma = math.sqrt(1. - e * e), math.sqrt(GM * a)
+    xfac1, xfac2 = a * (ccap - e), a * sqe * scap
+    ri = 1. / (a * (1. - e * ccap))
+    vfac1, vfac2 = -ri * sqgma * scap, ri * sqgma * sqe * ccap
+    sw, cw, so, co, si, ci = math.sin(w), math.cos(w), math.sin(O), math.cos(O), math.sin(i), math.cos(i)
+    d1 = (cw * co - sw * so * ci, cw * so + sw * co * ci, sw * si)
+    d2 = (-sw * co - cw * so * ci, -sw * so + cw * co * ci, cw * si)
+    return [d1[k] * xfac1 + d2[k] * xfac2 for k in range(3)] + [d1[k] * vfac1 + d2[k] * vfac2 for k in range(3)]
+
+
 def find_max_energy_conservation_error(ens, reference_ensemble):
     """swarm/utils.cpp:105-121"""
     e0, e1 = reference_ensemble.calc_total_energy(), ens.calc_total_energy()

@@ -79,6 +79,20 @@ def test_calc_keplerian_for_cartesian():
     assert a == pytest.approx(1.0) and e == pytest.approx(2.0) and M == pytest.approx(0.0, abs=1e-7)
 
 
+def test_keplerian_cartesian_round_trip():
+    import swarm_amd.swarmng as swarmng
+    rng = random.Random(3)
+    for _ in range(50):
+        el = [rng.uniform(0.5, 30), rng.uniform(0.01, 0.9), rng.uniform(0.05, 3.0), rng.uniform(0.1, 6.2),
+              rng.uniform(0.1, 6.2), rng.uniform(0.1, 6.2)]
+        GM = rng.uniform(0.5, 2.0)
+        xv = swarmng.calc_cartesian_for_keplerian(*el, GM=GM)
+        back = swarmng.calc_keplerian_for_cartesian(*xv, GM)
+        for k, (p, q) in enumerate(zip(el, back)):
+            d = abs(p - q) if k < 3 else abs((p - q + math.pi) % (2 * math.pi) - math.pi)
+            assert d < 1e-7, (k, el, back)
+
+
 def test_snapshot_files_interoperate_with_cli_and_reference_fixtures(tmp_path, oracle):
     """python text/binary I/O reads the reference's fixture and the C++ CLI's binary output"""
     import os
