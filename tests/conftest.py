@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The built artefacts are git-ignored.  In a tree where they are missing (a fresh checkout) and a
+    # compiler exists, build them once (hipcc cross-compiles gfx950 without a GPU); on the GPU box the
+    # prebuilt files travel with the tree and nothing is built.
+    need = [os.path.join(ROOT, "swarm_amd", "lib", "libswarm_hip.so"), os.path.join(ROOT, "swarm_amd", "lib", "libswarmng_hip.so"),
+            os.path.join(ROOT, "swarm_amd", "bin", "swarm"), os.path.join(ROOT, "swarm_amd", "bin", "swarm_nattr3"),
+            os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(f) for f in need) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
