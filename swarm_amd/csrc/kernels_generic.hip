@@ -14,6 +14,21 @@
 
 namespace swh {
 
+// sin and cos on [0, pi/4] by the fdlibm kernel polynomials (k_sin.c / k_cos.c, < 1 ulp / ~1 ulp): the
+// argument of the Stumpff functions is the eccentric-anomaly increment of one step, so it is almost always
+// in that range, and the library sincos() with its full range reduction costs three times as much.
+__device__ __forceinline__ void sincos_quarter(const double x, double &sn, double &cs) {
+    const double z = x * x;
+    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                      -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                      8.33333333332248946124e-03);
+    sn = __builtin_fma(x * z, __builtin_fma(z, rs, -1.66666666666666324348e-01), x);
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                      -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                      2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    cs = 1.0 - __builtin_fma(0.5, z, -(z * rc));
+}
+
 // ---- universal-variable Kepler drift: propagators/keplerian.hpp ------------------------------
 // SC_prussing, keplerian.hpp:61-87, including `float absy` and the float sqrt it selects.
 __device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
@@ -26,12 +41,15 @@ __device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
         double u3 = u * u * u;
         if (y > 0.0) {
             double sn, cs;
-            sincos(u, &sn, &cs);
-            S = (u - sn) / u3;
-            C = (1.0 - cs) / y;
+            if (u <= 0.78539816339744830962)
+                sincos_quarter(u, sn, cs);
+            else
+                sincos(u, &sn, &cs);
+            S = fdiv(u - sn, u3);
+            C = fdiv(1.0 - cs, y);
         } else {
-            S = (sinh(u) - u) / u3;
-            C = (cosh(u) - 1.0) / -y;
+            S = fdiv(sinh(u) - u, u3);
+            C = fdiv(cosh(u) - 1.0, -y);
         }
     }
 }

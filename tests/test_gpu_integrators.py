@@ -153,3 +153,17 @@ def test_irk2_no_convergence_disables_the_system_and_says_so(gpu, oracle):
     integ.set_destination_time(40.0)
     assert integ.integrate() == 3
     assert (h2.state == O.ACTIVE).all() and (h2.time == 0.0).all() and (h2.pos == e.pos).all()
+
+
+def test_mvs_in_the_trigonometric_regime_of_the_stumpff_functions(gpu, oracle):
+    """SC_prussing (keplerian.hpp:61-87) switches from its series to (u - sin u)/u^3, (1 - cos u)/y -- with u from a
+    float sqrt -- at |alpha x^2| >= 1e-4, i.e. when a step covers more than ~0.01 rad of eccentric anomaly.  Systems
+    shrunk to r = 0.15 ... 3 with dt = 0.01 exercise that branch (and both sin/cos paths of the kernel)."""
+    S, O = gpu, oracle
+    e = scaled(O, 128, 4, 0.015, 0.3, seed=8)
+    h = to_host(S, e)
+    integ = run_gpu(S, h, "mvs", {"time_step": "0.01"}, 1.0)
+    acc, _ = O.integrate(e, O.params("mvs", 1.0, time_step=0.01), threads=4, counters=True)
+    gacc, _ = integ.step_counts()
+    assert (gacc == acc.astype(np.uint64)).all() and (h.time == e.time).all() and (h.state == e.state).all()
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-9 and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < 1e-9
