@@ -490,8 +490,22 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
     }
     ms.ej_met = false;
     if (mp.ej_any) {
+        // One wave-uniform branch per call instead of one divergent branch per planet: at one wave per SIMD a
+        // taken branch stalls the wave while its instruction buffer refills.  `maybe` is the negation of the
+        // first early-out of test_body for any planet; the exact tests run only when some lane needs them.
+        bool maybe = false;
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body<N, VERBOSE>(s, b, mp, lg);
+            for (int b = 1; b < N; b++) {
+                const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                maybe = maybe || !(r2 < mp.r2_below);
+            }
+        }
+        if (__any(maybe)) {
+#pragma unroll
+            for (int b = 1; b < N; b++) ms.ej_met = ms.ej_met || ej_test_body<N, VERBOSE>(s, b, mp, lg);
+        }
         if (ms.ej_met && mp.ej_log) need_full = true;
     }
     if (mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && !need_full) { // short-circuit ||
@@ -530,6 +544,31 @@ template <int N, bool VERBOSE>
 __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonParams &mp,
                                          const LogBuf &lg, bool participate) {
     bool want = false;
+    if (mp.kind == SWARM_HIP_MON_EJECTION) {
+        // Common case of the common monitor, decided with two scalar branches: no planet of any lane of the
+        // wave is beyond rmax (r2 < r2_below is the first early-out of test_body), so nothing is met,
+        // nothing is logged, the state is unchanged.  Otherwise fall through to the general path.
+        bool maybe = false;
+        if (participate && mp.ej_any) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int b = 1; b < N; b++) {
+                const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                maybe = maybe || !(r2 < mp.r2_below);
+            }
+        }
+        if (!__any(maybe)) {
+            ms.ej_met = false;
+            return;
+        }
+    }
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) { // same early-out: no lane of the wave is due for a snapshot
+        const bool due = participate && mp.log_interval != 0. && s.t >= ms.next_log_time;
+        if (!__any(due)) {
+            ms.ej_met = false;
+            return;
+        }
+    }
     if (participate) {
         mon_pass_one<N, VERBOSE>(ms, s, mp, lg);
         mon_pass_two(ms, s, mp);

@@ -24,6 +24,11 @@ WORKLOADS = {
     # per system every 5 time units => 21 records x 288 B x 65536 = 396 MB of log per run
     "c5": dict(integrator="hermite_adap_log", nsys=65536, nbod=4, T=100.0,
                cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001", "log_interval": "5"}, log=420 << 20),
+    # Hermite.cfg with the ejection monitor armed (MON_ON variant of the kernel)
+    "c2_mon": dict(integrator="hermite", nsys=65536, nbod=3, T=1.0,
+                   cfg={"time_step": "0.0001", "deactivate_on_ejection": "1", "rmax": "1000"}),
+    # Gauss IRK, test/integrators/irk2.cfg step
+    "irk2": dict(integrator="irk2", nsys=65536, nbod=3, T=10.0, cfg={"time_step": "0.01"}),
     "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
                      cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
 }
