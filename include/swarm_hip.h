@@ -28,7 +28,7 @@ extern "C" {
 
 #define SWARM_HIP_CHUNK 64
 #define SWARM_HIP_MIN_NBOD 3
-#define SWARM_HIP_MAX_NBOD 8
+#define SWARM_HIP_MAX_NBOD 10
 
 /* error codes */
 #define SWARM_HIP_OK 0

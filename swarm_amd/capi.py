@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswarm_hip.so")
 
 CHUNK = 64
-MIN_NBOD, MAX_NBOD = 3, 8
+MIN_NBOD, MAX_NBOD = 3, 10
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP, IRK2, IRK2_CPU = range(1, 12)
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT, MON_LOG_TRANSIT = 0, 1, 2, 3, 4

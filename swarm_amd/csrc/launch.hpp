@@ -36,6 +36,8 @@ int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules);
     case 6: { constexpr int N = 6; CALL; } break;                          \
     case 7: { constexpr int N = 7; CALL; } break;                          \
     case 8: { constexpr int N = 8; CALL; } break;                          \
+    case 9: { constexpr int N = 9; CALL; } break;                          \
+    case 10: { constexpr int N = 10; CALL; } break;                        \
     default:                                                               \
         set_error("nbod=%d outside [%d,%d]", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD); \
         return SWARM_HIP_EINVAL;                                           \

@@ -24,7 +24,7 @@ def run_gpu(S, host, cfg, dest, counters=False):
     return integ
 
 
-@pytest.mark.parametrize("nbod", range(3, 9))
+@pytest.mark.parametrize("nbod", range(3, 11))
 def test_hermite_vs_reference_golden_files(gpu, oracle, nbod):
     """reference ctest scenario: Hermite.cfg (time_step=0.01) vs test.N.out.txt at 1e-8
     (cmake/test_integrators.cmake:33-39) -- and vs the oracle's hermite at the same dt at 1e-10"""

@@ -45,7 +45,7 @@ def run_gpu(S, host, name, cfg, dest, counters=True):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("nbod", [3, 4, 6, 8])
+@pytest.mark.parametrize("nbod", [3, 4, 6, 8, 10])
 def test_integrator_vs_oracle(gpu, oracle, name, nbod):
     S, O = gpu, oracle
     cfg, okw, T = CASES[name]

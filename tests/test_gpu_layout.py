@@ -32,7 +32,7 @@ def ref_image(e, RC, nbattr=1, nsattr=1):
     return body, sysb
 
 
-@pytest.mark.parametrize("nsys,nbod", [(1, 3), (64, 3), (65, 4), (1000, 6), (4099, 8)])
+@pytest.mark.parametrize("nsys,nbod", [(1, 3), (64, 3), (65, 4), (1000, 6), (4099, 8), (130, 10)])
 def test_upload_download_roundtrip(gpu, oracle, nsys, nbod):
     S, O = gpu, oracle
     e = perturbed(O, nsys, nbod, seed=2)
