@@ -233,23 +233,32 @@ static int launch_ns(const LaunchCtx &c, bool cpu_rules) {
     return check_launch("irk2 kernel launch");
 }
 
-template <int N>
-static int launch_n(const LaunchCtx &c, int method, bool cpu_rules) {
+// This file is compiled once per stage count (-DSWH_IRK2_NS=2|4|6, see the Makefile): the fully
+// unrolled s = 6 kernels dominate the library's build time, and three objects build in parallel.
+#ifndef SWH_IRK2_NS
+#error "compile with -DSWH_IRK2_NS=2, 4 or 6"
+#endif
+#define SWH_IRK2_CAT2(a, b) a##b
+#define SWH_IRK2_CAT(a, b) SWH_IRK2_CAT2(a, b)
+
+int SWH_IRK2_CAT(launch_irk2_s, SWH_IRK2_NS)(const LaunchCtx &c, bool cpu_rules) {
+    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_ns<N, SWH_IRK2_NS>(c, cpu_rules)));
+    return SWARM_HIP_OK;
+}
+
+#if SWH_IRK2_NS == 2
+int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
+    if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
+        if (int rc = mce_check_attributes(c)) return rc;
     switch (method) {
-    case 2: return launch_ns<N, 2>(c, cpu_rules);
-    case 4: return launch_ns<N, 4>(c, cpu_rules);
-    case 6: return launch_ns<N, 6>(c, cpu_rules);
+    case 2: return launch_irk2_s2(c, cpu_rules);
+    case 4: return launch_irk2_s4(c, cpu_rules);
+    case 6: return launch_irk2_s6(c, cpu_rules);
     default:
         set_error("irk2: method=%d, the number of stages must be 2, 4 or 6 (irk2_integrator.hpp:291,322,391)", method);
         return SWARM_HIP_EINVAL;
     }
 }
-
-int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
-    if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
-        if (int rc = mce_check_attributes(c)) return rc;
-    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N>(c, method, cpu_rules)));
-    return SWARM_HIP_OK;
-}
+#endif
 
 } // namespace swh

@@ -26,6 +26,9 @@ int launch_rkck(const LaunchCtx &c, bool adaptive);
 int launch_generic(const LaunchCtx &c, int integrator);
 // Gauss IRK; method = stages (2, 4, 6); cpu_rules = irk2_cpu's iteration constants and failure rule
 int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules);
+int launch_irk2_s2(const LaunchCtx &c, bool cpu_rules); // one object per stage count, kernels_irk2.hip
+int launch_irk2_s4(const LaunchCtx &c, bool cpu_rules);
+int launch_irk2_s6(const LaunchCtx &c, bool cpu_rules);
 
 // nbod -> template dispatch, the analogue of choose<> (swarm/gpu/helpers.hpp:97-107,216-238)
 #define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
