@@ -161,11 +161,30 @@ def test_hyperbolic_ejection_fixture(oracle):
 
 def test_close_orbits_ejection_fixture(oracle):
     """test/monitors/close_orbits: HermiteEjection.cfg on 4.in.txt -> HermiteEjection.4.out.txt.
-    These systems are chaotic over T=100, so only the bulk outcome is compared."""
+    These systems are chaotic over T=100 (and one of them spends >10^8 minimum-size steps in a captured pair under
+    the oracle's arithmetic), so the run itself is the GPU test's (test_gpu_monitors.py) and only the fixture's
+    bulk outcome is recorded here."""
     O = oracle
     d = os.path.join(GOLDEN, "monitors", "close_orbits")
     ref = O.load_text(os.path.join(d, "HermiteEjection.4.out.txt"))
     assert int((ref.state == O.DISABLED).sum()) == 11
+
+
+def test_close_orbits_close_encounter_fixture(oracle):
+    """test/monitors/close_orbits: HermiteCloseEncounter.cfg on 4.in.txt -> HermiteCloseEncounter.4.out.txt, written
+    by the reference's GPU `hermite_adap_close_encounter` (T=40, close_approach=0.01, deactivate).  Pins the
+    adaptive Hermite restatement together with stop_on_ejection_or_close_encounter: the same 15 systems stop at the
+    same times (2e-9), the others end within 2e-8 after T=40 of adaptive steps through near-encounters."""
+    O = oracle
+    d = os.path.join(GOLDEN, "monitors", "close_orbits")
+    e = O.load_text(os.path.join(d, "4.in.txt"))
+    ref = O.load_text(os.path.join(d, "HermiteCloseEncounter.4.out.txt"))
+    O.integrate(e, O.params("hermite_adap", 40.0, time_step_factor=0.017, min_time_step=1e-7),
+                O.monitor(kind=O.MON_EJECTION_OR_CLOSE, close_approach=0.01, deactivate_on_close_encounter=1), threads=4)
+    assert (e.state == ref.state).all() and int((ref.state == O.DISABLED).sum()) == 15
+    np.testing.assert_allclose(e.time, ref.time, rtol=0, atol=1e-8)
+    assert np.abs(e.pos - ref.pos).max() < 1e-7 and np.abs(e.vel - ref.vel).max() < 1e-7
+    assert (e.id == ref.id).all()
 
 
 @pytest.mark.parametrize("name,dt,kw", [("irk2_cpu", 1e-3, {}), ("irk2", 0.01, {}), ("irk2", 0.01, {"method": 4}),
