@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <vector>
+#include <mutex>
 
 #include "launch.hpp"
 
@@ -42,8 +42,16 @@ static int check_ens(const swarm_hip_ensemble_t *ens) {
                   ens->nbod, ens->nbattr, ens->nsattr, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD);
         return SWARM_HIP_EINVAL;
     }
+    if (ens->nsys > (1 << 30)) { // lane indices are 32-bit ints in the kernels; grid * block must not wrap
+        set_error("nsys=%d exceeds the supported maximum of 2^30 systems per ensemble", ens->nsys);
+        return SWARM_HIP_EINVAL;
+    }
     if (ens->nsys > 0 && (!ens->body || !ens->sysd || !ens->sysi)) {
         set_error("ensemble device pointers must not be NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (((uintptr_t)ens->body | (uintptr_t)ens->sysd) % sizeof(double) || (uintptr_t)ens->sysi % sizeof(int32_t)) {
+        set_error("ensemble device pointers must be aligned to their element size");
         return SWARM_HIP_EINVAL;
     }
     return SWARM_HIP_OK;
@@ -72,6 +80,8 @@ static int scratch_for_current(int32_t **out) {
         set_error("device ordinal %d out of range", dev);
         return SWARM_HIP_EINVAL;
     }
+    static std::mutex mu; // first use from two host threads on one device
+    std::lock_guard<std::mutex> lock(mu);
     if (!g_scratch[dev]) HIP_TRY(hipMalloc((void **)&g_scratch[dev], 256));
     *out = g_scratch[dev];
     return SWARM_HIP_OK;
@@ -668,15 +678,25 @@ int swarm_hip_free(void *d_ptr) {
     if (d_ptr) HIP_TRY(hipFree(d_ptr));
     return SWARM_HIP_OK;
 }
+static int check_copy(const char *what, const void *a, const void *b, size_t bytes) {
+    if (bytes && (!a || !b)) {
+        set_error("%s: NULL pointer with %zu bytes", what, bytes);
+        return SWARM_HIP_EINVAL;
+    }
+    return SWARM_HIP_OK;
+}
 int swarm_hip_memset(void *d_ptr, int value, size_t bytes, void *stream) {
+    if (int rc = check_copy("memset", d_ptr, d_ptr, bytes)) return rc;
     if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
     return SWARM_HIP_OK;
 }
 int swarm_hip_memcpy_d2h(void *host, const void *d_ptr, size_t bytes) {
+    if (int rc = check_copy("memcpy_d2h", host, d_ptr, bytes)) return rc;
     if (bytes) HIP_TRY(hipMemcpy(host, d_ptr, bytes, hipMemcpyDeviceToHost));
     return SWARM_HIP_OK;
 }
 int swarm_hip_memcpy_h2d(void *d_ptr, const void *host, size_t bytes) {
+    if (int rc = check_copy("memcpy_h2d", d_ptr, host, bytes)) return rc;
     if (bytes) HIP_TRY(hipMemcpy(d_ptr, host, bytes, hipMemcpyHostToDevice));
     return SWARM_HIP_OK;
 }
@@ -699,6 +719,10 @@ int swarm_hip_synchronize(void *stream) {
     return SWARM_HIP_OK;
 }
 int swarm_hip_event_create(void **event) {
+    if (!event) {
+        set_error("event_create: NULL out pointer");
+        return SWARM_HIP_EINVAL;
+    }
     hipEvent_t ev;
     HIP_TRY(hipEventCreate(&ev));
     *event = (void *)ev;
@@ -709,6 +733,10 @@ int swarm_hip_event_record(void *event, void *stream) {
     return SWARM_HIP_OK;
 }
 int swarm_hip_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!start || !stop || !ms) {
+        set_error("event_elapsed_ms: NULL argument");
+        return SWARM_HIP_EINVAL;
+    }
     HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return SWARM_HIP_OK;

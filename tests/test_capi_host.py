@@ -56,6 +56,16 @@ def test_argument_errors_without_gpu():
     assert capi.lib.swarm_hip_launch_integrator(C.byref(e), C.byref(a)) == -1
     with pytest.raises(capi.SwarmHipError):
         capi.check(capi.lib.swarm_hip_reactivate(C.byref(e), None))
+    e = capi.EnsembleStruct(16, capi.MAX_NBOD + 1, 1, 1, 8, 8, 8)
+    assert capi.lib.swarm_hip_launch_integrator(C.byref(e), C.byref(a)) == -1
+    e = capi.EnsembleStruct(16, 3, 1, 1, 8, 12, 8)             # sysd not 8-byte aligned
+    assert capi.lib.swarm_hip_launch_integrator(C.byref(e), C.byref(a)) == -1
+    assert b"aligned" in capi.lib.swarm_hip_last_error()
+    e = capi.EnsembleStruct((1 << 30) + 1, 3, 1, 1, 8, 8, 8)
+    assert capi.lib.swarm_hip_launch_integrator(C.byref(e), C.byref(a)) == -1
+    assert capi.lib.swarm_hip_launch_integrator(None, C.byref(a)) == -1
+    assert capi.lib.swarm_hip_memcpy_h2d(None, None, 16) == -1
+    assert capi.lib.swarm_hip_event_create(None) == -1
 
 
 def test_config_semantics(tmp_path):
