@@ -327,8 +327,11 @@ __device__ __forceinline__ double verlet_timestep(const State<N> &s, const IntPa
 }
 
 // ---------------------------------------------------------------------------------------------
+// MVS keeps two waves per SIMD (<= 256 registers, a few spilled doubles from nbod 5 on): its Kepler solver is a
+// chain of dependent FP64 operations with quarter-rate reciprocals, and a second resident wave hides them
+// (131072 x 5..8: -15..20 %; at one wave of work per SIMD, 65536 systems, +2..3 %).
 template <int N, int KIND, int MON>
-__global__ __launch_bounds__(256) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
+__global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= e.nsys) return;
