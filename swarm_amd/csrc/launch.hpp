@@ -31,6 +31,11 @@ int launch_irk2_s4(const LaunchCtx &c, bool cpu_rules);
 int launch_irk2_s6(const LaunchCtx &c, bool cpu_rules);
 
 // nbod -> template dispatch, the analogue of choose<> (swarm/gpu/helpers.hpp:97-107,216-238)
+#ifdef SWH_DISPATCH_ONLY /* kernel experiments: instantiate one nbod only (-DSWH_DISPATCH_ONLY=3), never in the shipped build */
+#define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
+    if (nbod == SWH_DISPATCH_ONLY) { constexpr int N = SWH_DISPATCH_ONLY; CALL; } \
+    else { set_error("experiment build: nbod=%d only", SWH_DISPATCH_ONLY); return SWARM_HIP_EINVAL; }
+#else
 #define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
     switch (nbod) {                                                        \
     case 3: { constexpr int N = 3; CALL; } break;                          \
@@ -45,6 +50,7 @@ int launch_irk2_s6(const LaunchCtx &c, bool cpu_rules);
         set_error("nbod=%d outside [%d,%d]", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD); \
         return SWARM_HIP_EINVAL;                                           \
     }
+#endif
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -90,15 +90,17 @@ def main():
                         attempts=attempts, flush_ms=(tf - tk) * 1e3, log_bytes=lm.bytes_flushed if lm else 0, dropped=lm.dropped if lm else 0,
                         states={int(k): int(v) for k, v in zip(*np.unique(host.state, return_counts=True))}))
     # host-to-host time of integrator.integrate(): upload (pack + H2D), kernel(s), flush, D2H + unpack
-    host = host0.clone()
-    integ = S.Integrator.create(S.config(cfg))
-    integ.set_ensemble(host)
-    integ.set_destination_time(T)
-    if w.get("log"):
-        integ.set_log_manager(S.LogManager(w["log"], "count"))
-    t0 = time.perf_counter()
-    integ.integrate()
-    e2e_ms = (time.perf_counter() - t0) * 1e3
+    e2e_ms = float("inf")
+    for _ in range(2):  # best of two: the host work above leaves the GPU idle long enough for its clock to drop
+        host = host0.clone()
+        integ = S.Integrator.create(S.config(cfg))
+        integ.set_ensemble(host)
+        integ.set_destination_time(T)
+        if w.get("log"):
+            integ.set_log_manager(S.LogManager(w["log"], "count"))
+        t0 = time.perf_counter()
+        integ.integrate()
+        e2e_ms = min(e2e_ms, (time.perf_counter() - t0) * 1e3)
     best = min(res, key=lambda r: r["ms"])
     best["host_to_host_ms"] = e2e_ms
     out = dict(workload=a.workload, integrator=w["integrator"], nsys=nsys, nbod=nbod, T=T, **best)

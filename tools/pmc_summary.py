@@ -11,6 +11,14 @@ for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recur
 res["kernels"].sort(key=lambda k: -k["pct"])
 dom = res["kernels"][0]["name"].split("(")[0] if res["kernels"] else None
 res["dominant"] = dom
+# per-launch durations of the dominant kernel (the first launch of a process, or one after an idle gap, runs at a
+# lower clock: the median is what the HIP-event timings of the same program report)
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f))
+               if dom and r["Kernel_Name"].startswith(dom))
+    if d:
+        res["dominant_launch_ns"] = {"launches": len(d), "min": d[0], "median": d[len(d) // 2] if len(d) % 2 else
+                                     (d[len(d) // 2 - 1] + d[len(d) // 2]) / 2, "max": d[-1]}
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
     for r in csv.DictReader(open(f)):
