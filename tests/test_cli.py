@@ -259,7 +259,7 @@ def test_reference_bdb_script_through_the_gpu_path(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8, 9, 10])
 def test_reference_hermite_cpu_cfg_reproduces_goldens(nbod):
     """test/integrators/Hermite_CPU.cfg is the configuration the golden outputs were generated with
     (test/integrators/generate.sh).  Run unchanged (integrator=hermite_cpu, nogpu=1) it must reproduce
