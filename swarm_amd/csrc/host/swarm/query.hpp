@@ -1,7 +1,7 @@
 // swarm/query.hpp -- binary log files and the `swarm query` text dump.
 // Mirrors swarm/log/fileformat.hpp (swarm_header), swarm/log/io.{hpp,cpp} (sorting, ranges) and
-// swarm/query.{hpp,cpp} (record formatting) for EVT_SNAPSHOT records in Cartesian output.
-// Keplerian output (-k) and the .db (Berkeley DB) files are not provided.
+// swarm/query.{hpp,cpp} (record formatting: Cartesian and Keplerian (-k) output of EVT_SNAPSHOT records,
+// transit/occultation events).  The .db (Berkeley DB) files are not provided.
 #pragma once
 #include <cstdint>
 #include <cstring>

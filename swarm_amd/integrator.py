@@ -58,6 +58,57 @@ PLUGINS = {
 }
 
 
+class BinaryWriter:
+    """log::binary_writer (swarm/log/binary_writer.cpp:39-91): the raw record stream behind a 96-byte
+    swarm_header in `<log_output>.raw`; close() sorts it by (time, system, position) into `<log_output>`
+    (swarm/log/io.cpp:226-264) and removes the raw file.  Same bytes as the C++ host mirror writes."""
+
+    UNSORTED = b"unsorted_output // Unsorted output file"
+    SORTED = b"T_sorted_output // Output file sorted by time"
+
+    @staticmethod
+    def header(kind, datalen=0xFFFFFFFFFFFFFFFF):
+        import struct
+        return struct.pack("<6s2s76sIQ", b"SWARM", b"0", kind, 0, datalen)   # fileformat.hpp:28-68
+
+    def __init__(self, cfg):
+        self.binfn = cfg.optional("log_output", "")
+        if self.binfn == "":
+            raise runtime_error("Expected filename for writer.")
+        self.rawfn = self.binfn + ".raw"
+        self._f = open(self.rawfn, "wb")
+        self._f.write(self.header(self.UNSORTED))
+
+    def process(self, data):
+        if data:
+            self._f.write(data)
+
+    def close(self):
+        if self._f is None:
+            return
+        self._f.close()
+        self._f = None
+        import os
+        import struct
+        raw = open(self.rawfn, "rb").read()[96:]
+        recs = []
+        for pos, (msgid, rec) in enumerate(gpulog.records(raw)):
+            t, s = struct.unpack_from("<di", rec, 8)
+            recs.append((t, s, pos, rec))
+        recs.sort(key=lambda r: r[:3])
+        with open(self.binfn, "wb") as out:
+            out.write(self.header(self.SORTED, len(raw)))
+            for r in recs:
+                out.write(r[3])
+        os.unlink(self.rawfn)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LogManager:
     """log::manager (swarm/log/logmanager.cpp:50-87): owns the device event buffer; flush() copies
     the used bytes to the host and clears the device cursor.  The default log has 0-byte buffers
@@ -98,7 +149,15 @@ class LogManager:
             return LogManager(device_bytes, None)
         if w == "host_array":
             return LogManager(device_bytes, "host")
+        if w == "binary":
+            return LogManager(device_bytes, BinaryWriter(cfg))
         raise plugin_not_found("writer_" + w)
+
+    def close(self):
+        """flush what is left and finish the writer (the binary writer sorts its file here)"""
+        self.flush()
+        if hasattr(self.writer, "close"):
+            self.writer.close()
 
     def struct(self):
         if not self.capacity:

@@ -3,10 +3,14 @@ the reference, which needs boost.python and Python 2): the same names and call s
 package's ctypes binding, so scripts like py/tests/trivial.py run with `import swarm_amd.swarmng as
 swarmng`.  Ensembles are views onto HostEnsemble's numpy arrays."""
 import math
+import os
 
 import numpy as np
 
 from . import capi
+from . import logdb, logrecord, range_type
+from . import logquery as query
+from .logrecord import KeplerianCoordinates, keplerian_for_cartesian
 from . import snapshot as _snap
 from .config import config as _config
 from .ensemble import HostEnsemble
@@ -16,9 +20,36 @@ from .integrator import Integrator as _Integrator
 from .integrator import LogManager
 
 
+SWARMDIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))   # py/swarmng/__init__.py:22
+
+
+_default_log = None   # log::manager::default_log(), logmanager.cpp:37-47
+
+
+def _close_default_log():
+    global _default_log
+    if _default_log is not None:
+        _default_log.close()
+        _default_log = None
+
+
 def init(cfg):
-    """swarm::init(cfg), swarm/swarm.h:49"""
+    """swarm::init(cfg), swarm/swarm.h:49-77: select the device, then initialise the default log from
+    `log_writer` (null | host_array | binary + `log_output`); every integrator created afterwards logs there
+    (integrator.cpp:51).  The binary writer's file is sorted and finished when the process exits, when init()
+    is called again, or on shutdown()."""
+    global _default_log
     capi.check(capi.lib.swarm_hip_init(cfg.optional("HIP_DEVICE", cfg.optional("CUDA_DEVICE", 0))))
+    _close_default_log()
+    if cfg.optional("log_writer", "null") != "null":
+        import atexit
+        _default_log = LogManager.from_config(cfg)
+        atexit.register(_close_default_log)
+
+
+def shutdown():
+    """log::manager::shutdown(), logmanager.cpp:59-64: back to the null writer"""
+    _close_default_log()
 
 
 def sync():
@@ -180,7 +211,7 @@ class Integrator:
 
     @staticmethod
     def create(cfg):
-        return GpuIntegrator(_Integrator.create(cfg))
+        return GpuIntegrator._with_default_log(_Integrator.create(cfg))
 
     def integrate(self):
         self._impl.integrate()
@@ -198,8 +229,14 @@ class Integrator:
 
 class GpuIntegrator(Integrator):
     @staticmethod
+    def _with_default_log(impl):
+        if _default_log is not None:
+            impl.set_log_manager(_default_log)
+        return GpuIntegrator(impl)
+
+    @staticmethod
     def create(cfg):
-        return GpuIntegrator(_Integrator.create(cfg))
+        return GpuIntegrator._with_default_log(_Integrator.create(cfg))
 
     def core_integrate(self):
         return self._impl.core_integrate()
