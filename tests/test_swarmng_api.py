@@ -171,3 +171,57 @@ def test_ejection_test():
                         assert s.state == -1, "a system with an ejected body should be disabled"
             assert sum(1 for s in self.ens if s.state == -1) > 0 or n_ejected == 0
     T().run(swarmng)
+
+
+@pytest.mark.gpu
+def test_tutorial_flows(tmp_path):
+    """py/tutorial.py, py/resume_tutorial.py and py/stats_tutorial.py, statement by statement, over the
+    reference's own data file test/integrators/test.3.in.txt (tests/golden/integrators)."""
+    import os
+    import swarm_amd.swarmng as swarmng
+    from conftest import GOLDEN
+    # ---- tutorial.py
+    swarmng.init(swarmng.config(nogpu=1))
+    ref = swarmng.DefaultEnsemble.load_from_text(os.path.join(GOLDEN, "integrators", "test.3.in.txt"))
+    lines = []
+    for s in ref:
+        lines.append("System {0}, time: {1}, state: {2} ".format(s.id, s.time, s.state))
+        for i, b in enumerate(s):
+            lines.append("\tBody {0} pos: {1}\tvel:{2}".format(i, b.pos, b.vel))
+    assert len(lines) == 16 * 4
+    ref[3][0].pos = [1.0, 2.0, 5.0]
+    assert list(ref[3][0].pos) == [1.0, 2.0, 5.0]
+    ref[3][0].pos = [0.0, 0.0, 0.0]
+    ens = ref.clone()
+    integ = swarmng.Integrator.create(swarmng.config(integrator="hermite_cpu", time_step=0.001))
+    integ.ensemble = ens
+    integ.destination_time = 1.0
+    integ.integrate()
+    first = swarmng.DefaultEnsemble.load_from_text(os.path.join(GOLDEN, "integrators", "test.3.out.txt"))
+    assert max(abs(a - b) for s, r in zip(ens, first) for p, q in zip(s, r) for a, b in zip(p.pos, q.pos)) < 1e-10
+    integ.destination_time = 2.0
+    integ.integrate()                                  # systems carry their own time: this resumes at t=1
+    assert all(abs(s.time - 2.0) < 1e-9 for s in ens)
+    assert swarmng.find_max_energy_conservation_error(ens, ref) < 1e-9
+    # ---- resume_tutorial.py: snapshot, reload, continue from the median system time
+    snap = str(tmp_path / "in.bin.snapshot")
+    ens.save_to_bin(snap)
+    again = swarmng.DefaultEnsemble.load_from_bin(snap)
+    times = sorted(map(lambda s: s.time, again))
+    starting_time = times[len(times) // 2]
+    integ = swarmng.Integrator.create(swarmng.config(integrator="hermite_cpu", time_step=0.001))
+    integ.ensemble = again
+    integ.destination_time = starting_time + 0.5
+    integ.integrate()
+    assert all(abs(s.time - 2.5) < 1e-9 for s in again)
+    # ---- stats_tutorial.py: astrocentric elements of every planet through keplerian_for_cartesian
+    value = np.empty((again.nbod - 1, 6, again.nsys))
+    for sysid, s in enumerate(again):
+        star = s[0]
+        center = (star.pos, star.vel, star.mass)
+        for bodid in range(1, again.nbod):
+            bod = s[bodid]
+            value[bodid - 1, :, sysid] = swarmng.keplerian_for_cartesian((bod.pos, bod.vel, bod.mass), center)
+    r0 = [np.mean([s[b].distance_to_origin() for s in ref]) for b in (1, 2)]      # circular orbits at t=0
+    assert abs(np.average(value[0, 0, :]) / r0[0] - 1) < 0.01 and abs(np.average(value[1, 0, :]) / r0[1] - 1) < 0.01
+    assert np.average(value[:, 1, :]) < 0.02 and (value[:, 2, :] == 0).all()
