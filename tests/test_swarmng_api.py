@@ -225,3 +225,20 @@ def test_tutorial_flows(tmp_path):
     r0 = [np.mean([s[b].distance_to_origin() for s in ref]) for b in (1, 2)]      # circular orbits at t=0
     assert abs(np.average(value[0, 0, :]) / r0[0] - 1) < 0.01 and abs(np.average(value[1, 0, :]) / r0[1] - 1) < 0.01
     assert np.average(value[:, 1, :]) < 0.02 and (value[:, 2, :] == 0).all()
+
+
+@pytest.mark.gpu
+def test_benchmark_script_flow():
+    """py/benchmark.py: one `hermite` integrator object, re-used for generated ensembles of 8000 systems with
+    3..6 bodies (the device ensemble is re-created when the shape changes), T=10, dt=1e-3"""
+    import swarm_amd.swarmng as swarmng
+    swarmng.init(swarmng.config(CUDA_DEVICE=0, verbose=1))
+    integ = swarmng.Integrator.create(swarmng.config(integrator="hermite", time_step=0.001))
+    for nb in range(3, 7):
+        ens = swarmng.generate_ensemble(swarmng.config(nsys=8000, nbod=nb))
+        ref = ens.clone()
+        integ.ensemble = ens
+        integ.destination_time = 10.0
+        integ.integrate()
+        assert ens.nbod == nb and all(abs(s.time - 10.0) < 1e-9 and s.state == 1 for s in ens)
+        assert swarmng.find_max_energy_conservation_error(ens, ref) < 1e-7
