@@ -37,7 +37,7 @@ class LaunchStruct(C.Structure):
                 ("verbose_on_ejection", C.c_int32), ("deactivate_on_close_encounter", C.c_int32),
                 ("log_on_close_encounter", C.c_int32), ("verbose_on_close_encounter", C.c_int32),
                 ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double), ("irk2_method", C.c_int32), ("log_transits", C.c_int32), ("log_occultations", C.c_int32),
-                ("reserved0", C.c_int32), ("log_transit_tol", C.c_double),
+                ("lane_mode", C.c_int32), ("log_transit_tol", C.c_double),
                 ("log", LogStruct),
                 ("d_steps_accepted", C.c_void_p), ("d_steps_attempted", C.c_void_p),
                 ("stream", C.c_void_p)]

@@ -426,6 +426,11 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
         return SWARM_HIP_EINVAL;
     }
     c.grid = grid_for(ens->nsys, c.block);
+    if (a->lane_mode < 0 || a->lane_mode > 2) {
+        set_error("lane_mode=%d must be 0 (automatic), 1 (lane per system) or 2 (lane per body)", a->lane_mode);
+        return SWARM_HIP_EINVAL;
+    }
+    c.lane_mode = a->lane_mode;
     c.stream = (hipStream_t)a->stream;
 
     switch (a->integrator) {

@@ -8,6 +8,7 @@
 
 namespace swh {
 
+
 template <int N, bool ADAPTIVE, int MON>
 __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
@@ -140,10 +141,21 @@ static int launch_n(const LaunchCtx &c) {
     return check_launch("hermite kernel launch");
 }
 
+// One lane per body pays while the ensemble is too small to give every SIMD a wavefront of whole systems;
+// beyond the measured crossover (tools/lane_sweep.sh, DESIGN 5: nsys ~ 8k for nbod 3, 16-24k for nbod 4..9,
+// 33k for nbod 10) the lane-per-system kernel's throughput wins.  Limits sit a little below the crossovers.
+static bool small_ensemble(const LaunchCtx &c) {
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 16384, 12288, 16384, 16384, 20480, 16384, 28672};
+    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+}
+
 int launch_hermite(const LaunchCtx &c, bool adaptive) {
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {
+        // small ensembles with nothing to monitor: one lane per body (kernels_hermite_body.hip)
+        if (monitor_variant(c.mp) == MON_OFF && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c))))
+            return launch_hermite_body(c);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, false>(c)));
     }
     return SWARM_HIP_OK;

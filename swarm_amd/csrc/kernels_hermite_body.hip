@@ -1,0 +1,159 @@
+// kernels_hermite_body.hip -- fixed-step PEC2 Hermite with ONE LANE PER BODY, for small ensembles.
+//
+// The one-lane-per-system kernel (kernels_hermite.hip) needs >= 65536 systems to put one wavefront
+// on every SIMD; below that its run time is the latency of one wave's dependent steps whatever nsys
+// is (the reference's saturation sweep, scripts/saturation: nsys = 32 ... 32768, is flat).  Here the
+// nbod bodies of a system sit in nbod adjacent lanes (floor(64/nbod) systems per wavefront): a lane
+// predicts and corrects its own body and sums the forces of its nbod-1 partners, whose predicted
+// positions and velocities it reads from the partner lanes (ds_bpermute).  The dependent chain per
+// step is about nbod/2.5 times shorter, at the price of computing every pair on both sides.
+//
+// Arithmetic is that of accjerk<N> / hermite_step<N> (device_common.hpp) operation for operation:
+// a body accumulates its partners in increasing index order, first term by multiplication, and
+// (p_j - p_i), (v_j - v_i) enter the pair quantities only through products that are even in the
+// sign, so both kernels give bit-identical ensembles (tests/test_gpu_hermite.py).
+// Used by launch_hermite for the no-op monitor only (Hermite.cfg as shipped: no deactivate/log keys).
+#include "launch.hpp"
+
+namespace swh {
+
+template <int N>
+__global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, Counters cnt) {
+    constexpr int G = W / N; // systems per wavefront
+    const int lane = threadIdx.x;
+    const int g = lane / N, b = lane - g * N;
+    const long long sys_ll = (long long)blockIdx.x * G + g;
+    const bool valid = lane < G * N && sys_ll < e.nsys;
+    const int sys = valid ? (int)sys_ll : 0;
+    const int base = g * N; // first lane of my system
+
+    // own body, the partners' masses, the system's time and state (every lane of a group holds a copy)
+    const size_t chunk = sys / W, sl = sys % W;
+    double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
+    double p[3], v[3], mo[N - 1], t = 0.0;
+    int state = SWARM_HIP_DISABLED;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
+        v[c] = valid ? row[(3 + c) * W] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < N - 1; q++) {
+        const int j = q < b ? q : q + 1; // partners in increasing index order
+        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+    }
+    if (valid) {
+        t = e.sysd[chunk * e.nsf * W + sl];
+        state = e.sysi[chunk * 2 * W + sl];
+    }
+    const int state_in = state;
+
+    // forces on my body from the current p, v of all lanes; wave-wide (shuffles), no divergence inside
+    auto forces = [&](double (&a)[3], double (&jk)[3]) {
+#pragma unroll
+        for (int q = 0; q < N - 1; q++) {
+            const int src = base + (q < b ? q : q + 1);
+            const double d0 = __shfl(p[0], src) - p[0], d1 = __shfl(p[1], src) - p[1], d2 = __shfl(p[2], src) - p[2];
+            const double e0 = __shfl(v[0], src) - v[0], e1 = __shfl(v[1], src) - v[1], e2 = __shfl(v[2], src) - v[2];
+            const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+            const double xv = __builtin_fma(d2, e2, __builtin_fma(d1, e1, d0 * e0));
+            const double y = rsqrt_full(r2);
+            const double y2 = y * y;
+            const double rinv = y * y2;
+            const double rv = (xv * 3.0) * y2;
+            const double sc = rinv * mo[q];
+            const double t0 = __builtin_fma(-d0, rv, e0), t1 = __builtin_fma(-d1, rv, e1), t2 = __builtin_fma(-d2, rv, e2);
+            if (q == 0) {
+                a[0] = d0 * sc, a[1] = d1 * sc, a[2] = d2 * sc;
+                jk[0] = t0 * sc, jk[1] = t1 * sc, jk[2] = t2 * sc;
+            } else {
+                a[0] = __builtin_fma(d0, sc, a[0]), a[1] = __builtin_fma(d1, sc, a[1]), a[2] = __builtin_fma(d2, sc, a[2]);
+                jk[0] = __builtin_fma(t0, sc, jk[0]), jk[1] = __builtin_fma(t1, sc, jk[1]);
+                jk[2] = __builtin_fma(t2, sc, jk[2]);
+            }
+        }
+    };
+
+    unsigned long long steps = 0;
+    double a0[3], j0[3];
+    forces(a0, j0);
+    const double dest = ip.destination_time;
+    StepConsts k;
+    k.set(ip.time_step);
+    int iter = 0;
+    bool active = valid && state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
+    // Every lane walks through every step of the slowest system of its wave (the shuffles need all lanes);
+    // lanes of finished or idle groups compute and discard.
+    while (__any(active)) {
+        double h = ip.time_step;
+        {
+#pragma clang fp contract(off)
+            if (t + h > dest) h = dest - t; // hermite_integrator.hpp:120-123
+        }
+        if (h != k.h) k.set(h);
+        const double p_in[3] = {p[0], p[1], p[2]}, v_in[3] = {v[0], v[1], v[2]};
+        double pp[3], pv[3], c0[3], dd0[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { // hermite_step<N>, predictor
+            pp[c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[c], a0[c]), v[c]), p[c]);
+            pv[c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[c], a0[c]), v[c]);
+            p[c] = pp[c];
+            v[c] = pv[c];
+            c0[c] = k.kp_j0 * j0[c];
+            pp[c] = __builtin_fma(k.kp_a, a0[c], pp[c]);
+            dd0[c] = __builtin_fma(k.kv_a, a0[c], k.kv_j0 * j0[c]);
+        }
+        double a1[3], j1[3];
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            forces(a1, j1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                p[c] = __builtin_fma(-k.kp_a, a1[c], pp[c]) + __builtin_fma(k.kp_j1, j1[c], c0[c]);
+                v[c] = pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) a0[c] = a1[c], j0[c] = j1[c];
+            t += h;
+            steps++;
+            iter++;
+            {
+#pragma clang fp contract(off)
+                if (t > dest - 1e-12) state = SWARM_HIP_INACTIVE; // hermite_integrator.hpp:177-179
+            }
+            active = state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
+        } else { // a finished system keeps its state while the rest of the wave goes on
+#pragma unroll
+            for (int c = 0; c < 3; c++) p[c] = p_in[c], v[c] = v_in[c];
+        }
+    }
+    if (valid && (steps || state != state_in)) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            row[c * W] = p[c];
+            row[(3 + c) * W] = v[c];
+        }
+        if (b == 0) {
+            e.sysd[chunk * e.nsf * W + sl] = t;
+            e.sysi[chunk * 2 * W + sl] = state;
+        }
+    }
+    if (valid && b == 0) {
+        if (cnt.accepted) cnt.accepted[sys] += steps;
+        if (cnt.attempted) cnt.attempted[sys] += steps;
+    }
+}
+
+// one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
+int launch_hermite_body(const LaunchCtx &c) {
+    SWH_DISPATCH_NBOD(c.ens.nbod, {
+        constexpr int G = W / N;
+        const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+        hipLaunchKernelGGL((hermite_body_kernel<N>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.cnt);
+    });
+    return check_launch("hermite (lane per body) kernel launch");
+}
+
+} // namespace swh

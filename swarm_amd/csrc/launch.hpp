@@ -14,6 +14,7 @@ struct LaunchCtx {
     Counters cnt;
     int block;      // threads per workgroup
     int grid;       // workgroups
+    int lane_mode;  // swarm_hip_launch_t::lane_mode
     hipStream_t stream;
 };
 
@@ -21,6 +22,7 @@ void set_error(const char *fmt, ...);
 
 // one entry per kernel translation unit; each dispatches on nbod
 int launch_hermite(const LaunchCtx &c, bool adaptive);
+int launch_hermite_body(const LaunchCtx &c); // one lane per body, small ensembles (kernels_hermite_body.hip)
 int launch_hermite_mce(const LaunchCtx &c); // `hermite` + mce_stat (plugins/hermite.cu:40)
 int launch_rkck(const LaunchCtx &c, bool adaptive);
 int launch_generic(const LaunchCtx &c, int integrator);

@@ -24,15 +24,16 @@ def run_gpu(S, host, cfg, dest, counters=False):
     return integ
 
 
+@pytest.mark.parametrize("lane_mode", [1, 2])     # both kernels: 16 systems would select lane-per-body by itself
 @pytest.mark.parametrize("nbod", range(3, 11))
-def test_hermite_vs_reference_golden_files(gpu, oracle, nbod):
+def test_hermite_vs_reference_golden_files(gpu, oracle, nbod, lane_mode):
     """reference ctest scenario: Hermite.cfg (time_step=0.01) vs test.N.out.txt at 1e-8
     (cmake/test_integrators.cmake:33-39) -- and vs the oracle's hermite at the same dt at 1e-10"""
     S, O = gpu, oracle
     e = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
     ref = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.out.txt" % nbod))
     h = to_host(S, e)
-    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.01"}, 1.0)
+    run_gpu(S, h, {"integrator": "hermite", "time_step": "0.01", "lane_mode": str(lane_mode)}, 1.0)
     pd = np.sqrt(((h.pos - ref.pos) ** 2).sum(-1)).max()
     vd = np.sqrt(((h.vel - ref.vel) ** 2).sum(-1)).max()
     assert pd < 1e-8 and vd < 1e-8
@@ -46,14 +47,15 @@ def test_hermite_vs_reference_golden_files(gpu, oracle, nbod):
         assert (h.state == o.state).all()
 
 
+@pytest.mark.parametrize("lane_mode", [1, 2])
 @pytest.mark.parametrize("nbod,nsys,dt,T", [(3, 1000, 1e-3, 1.0), (4, 333, 1e-3, 1.0), (6, 129, 1e-3, 0.5),
                                             (8, 64, 2e-3, 0.5), (3, 65, 1e-4, 1.0)])
-def test_hermite_vs_hermite_cpu_on_perturbed_ensembles(gpu, oracle, nbod, nsys, dt, T):
+def test_hermite_vs_hermite_cpu_on_perturbed_ensembles(gpu, oracle, nbod, nsys, dt, T, lane_mode):
     S, O = gpu, oracle
     e = perturbed(O, nsys, nbod, seed=nbod)
     e0 = e.clone()
     h = to_host(S, e)
-    integ = run_gpu(S, h, {"integrator": "hermite", "time_step": repr(dt)}, T, counters=True)
+    integ = run_gpu(S, h, {"integrator": "hermite", "time_step": repr(dt), "lane_mode": str(lane_mode)}, T, counters=True)
     acc, att = O.integrate(e, O.params("hermite_cpu", T, time_step=dt), threads=4, counters=True)
     assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
     assert np.abs(h.pos[:, 0] - e.pos[:, 0]).max() < TOL
@@ -170,3 +172,60 @@ def test_energy_error_distribution_matches_hermite_cpu_in_the_rounding_dominated
     assert eo.max() < 1e-13
     assert eg.max() < 1e-13 and eg.max() < 3 * eo.max() and np.median(eg) < 3 * np.median(eo)
     assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < 1e-12 and (h.time == e.time).all()
+
+
+@pytest.mark.parametrize("nbod,nsys", [(3, 1000), (4, 257), (5, 100), (6, 64), (7, 19), (8, 300), (9, 8), (10, 33)])
+def test_lane_per_body_kernel_is_bit_identical(gpu, oracle, nbod, nsys):
+    """lane_mode=2 (one lane per body, kernels_hermite_body.hip) against lane_mode=1 (one lane per system): the same
+    operations in the same order => identical bits, for ragged wave tails (64 % nbod idle lanes, nsys not a multiple
+    of the systems per wavefront), systems with different start times and states, a clipped last step and an
+    iteration budget that ends mid-way."""
+    S, O = gpu, oracle
+    e = perturbed(O, nsys, nbod, seed=100 + nbod)
+    e.time[:] = np.linspace(0.0, 0.0037, nsys)          # own times: systems of one wave finish at different steps
+    e.state[5::13] = O.INACTIVE                         # re-activated by integrate()
+    e.state[3::11] = O.DISABLED
+    res = {}
+    for mode in (1, 2):
+        h = to_host(S, e)
+        integ = S.Integrator.create(S.config({"integrator": "hermite", "time_step": "0.001", "lane_mode": str(mode)}))
+        integ.set_ensemble(h)
+        integ.set_destination_time(0.25037)             # not a multiple of the step: clipped last step
+        integ.enable_step_counters()
+        integ.integrate()
+        res[mode] = (h, integ.step_counts())
+    (h1, c1), (h2, c2) = res[1], res[2]
+    for k in ("pos", "vel", "time", "state", "id", "mass"):
+        assert (getattr(h1, k) == getattr(h2, k)).all(), k
+    assert (c1[0] == c2[0]).all() and (c1[1] == c2[1]).all() and c1[0].max() == 251
+    assert (h2.state[3::11] == O.DISABLED).all() and (h2.time[3::11] == e.time[3::11]).all()
+    # budget: 100 steps per launch, 3 launches to finish
+    h = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "hermite", "time_step": "0.001", "lane_mode": "2", "max_iterations": "100"}))
+    integ.set_ensemble(h)
+    integ.set_destination_time(0.25037)
+    assert integ.integrate() == 3
+    assert (h.pos == h1.pos).all() and (h.vel == h1.vel).all() and (h.time == h1.time).all() and (h.state == h1.state).all()
+    # and against the oracle's hermite_cpu like every other Hermite test
+    o = e.clone()
+    o.state[o.state == O.INACTIVE] = O.ACTIVE
+    O.integrate(o, O.params("hermite_cpu", 0.25037, time_step=0.001), threads=4)
+    assert rel_diff(h2.pos[:, 1:], o.pos[:, 1:]) < 1e-10 and (h2.state == o.state).all()
+
+
+def test_lane_mode_selection_and_errors(gpu, oracle):
+    """lane_mode=0 picks the lane-per-body kernel for small ensembles with a no-op monitor and the lane-per-system
+    kernel otherwise; either way the result is the same bits.  An armed monitor always takes lane-per-system."""
+    S, O = gpu, oracle
+    e = perturbed(O, 500, 4, seed=3)
+    out = []
+    for cfg in ({"lane_mode": "0"}, {"lane_mode": "1"}, {"lane_mode": "2"},
+                {"lane_mode": "2", "deactivate_on_ejection": "1", "rmax": "1000"}):
+        h = to_host(S, e)
+        run_gpu(S, h, dict(cfg, integrator="hermite", time_step="0.001"), 0.3)
+        out.append(h)
+    for h in out[1:]:
+        assert (h.pos == out[0].pos).all() and (h.vel == out[0].vel).all() and (h.time == out[0].time).all()
+    h = to_host(S, e)
+    with pytest.raises(S.capi.SwarmHipError, match="lane_mode"):
+        run_gpu(S, h, {"integrator": "hermite", "time_step": "0.001", "lane_mode": "3"}, 0.3)

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--T", type=float)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--lane-mode", type=int, default=0, help="0 auto, 1 lane per system, 2 lane per body (hermite)")
     ap.add_argument("--spread", type=float, default=0.0, help="scale systems geometrically by up to this factor")
     a = ap.parse_args()
     w = dict(WORKLOADS[a.workload])
@@ -53,7 +54,7 @@ def main():
         s = np.geomspace(1.0 / a.spread, 1.0, nsys)[:, None, None]
         host0.pos *= s
         host0.vel /= np.sqrt(s)
-    cfg = dict(w["cfg"], integrator=w["integrator"])
+    cfg = dict(w["cfg"], integrator=w["integrator"], lane_mode=str(a.lane_mode))
     res = []
     for rep in range(a.reps):
         host = host0.clone()
