@@ -154,8 +154,10 @@ int launch_hermite(const LaunchCtx &c, bool adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {
         // small ensembles with nothing to monitor: one lane per body (kernels_hermite_body.hip)
-        if (monitor_variant(c.mp) == MON_OFF && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c))))
-            return launch_hermite_body(c);
+        // ... or only stop_on_ejection's deactivation (no records, no printf): each lane tests its own planet
+        const int variant = monitor_variant(c.mp);
+        const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
+        if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, false>(c)));
     }
     return SWARM_HIP_OK;

@@ -12,13 +12,32 @@
 // a body accumulates its partners in increasing index order, first term by multiplication, and
 // (p_j - p_i), (v_j - v_i) enter the pair quantities only through products that are even in the
 // sign, so both kernels give bit-identical ensembles (tests/test_gpu_hermite.py).
-// Used by launch_hermite for the no-op monitor only (Hermite.cfg as shipped: no deactivate/log keys).
+// Used by launch_hermite for the no-op monitor (Hermite.cfg as shipped: no deactivate/log keys) and, EJ = true,
+// for stop_on_ejection with deactivate_on_ejection only (nothing to log or print): every lane tests its own
+// planet (stop_on_ejection.hpp:108-138) and the lanes of a system share the verdict through one ballot.
 #include "launch.hpp"
 
 namespace swh {
 
-template <int N>
-__global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, Counters cnt) {
+// test_body without the verbose branch; same operations as ej_test_body (device_common.hpp)
+__device__ __forceinline__ bool ej_test_quiet(const double (&p)[3], const double (&v)[3], const double m,
+                                              const MonParams &mp) {
+#pragma clang fp contract(off)
+    const double x = p[0], y = p[1], z = p[2];
+    const double r2 = x * x + y * y + z * z;
+    if (r2 < mp.r2_below) return false;
+    const double vx = v[0], vy = v[1], vz = v[2];
+    const double r = sqrt(r2);
+    if (r < mp.rmax) return false;
+    const double rdotv = x * vx + y * vy + z * vz;
+    if (rdotv <= 0.) return false;
+    const double speed_sq = vx * vx + vy * vy + vz * vz;
+    const double epp = 0.5 * speed_sq * r / m - 1.;
+    return fabs(epp) < 1e-4 || epp > 0;
+}
+
+template <int N, bool EJ>
+__global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
@@ -31,6 +50,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     const size_t chunk = sys / W, sl = sys % W;
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
     double p[3], v[3], mo[N - 1], t = 0.0;
+    const double m_own = (EJ && valid) ? row[6 * W] : 1.0;
+    const unsigned long long group_mask = ((1ull << N) - 1) << base; // lanes of my system (base + N <= 64 when valid)
     int state = SWARM_HIP_DISABLED;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -119,7 +140,14 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             t += h;
             steps++;
             iter++;
-            {
+        }
+        if (EJ) { // stop_on_ejection::operator(), after the step and before the end-of-integration test
+            const bool ej = active && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+            const bool met = (__ballot(ej) & group_mask) != 0;
+            if (active && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+        }
+        if (active) {
+            if (state == SWARM_HIP_ACTIVE) {
 #pragma clang fp contract(off)
                 if (t > dest - 1e-12) state = SWARM_HIP_INACTIVE; // hermite_integrator.hpp:177-179
             }
@@ -151,7 +179,10 @@ int launch_hermite_body(const LaunchCtx &c) {
     SWH_DISPATCH_NBOD(c.ens.nbod, {
         constexpr int G = W / N;
         const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-        hipLaunchKernelGGL((hermite_body_kernel<N>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.cnt);
+        if (monitor_variant(c.mp) == MON_OFF)
+            hipLaunchKernelGGL((hermite_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+        else
+            hipLaunchKernelGGL((hermite_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
     });
     return check_launch("hermite (lane per body) kernel launch");
 }

@@ -229,3 +229,31 @@ def test_lane_mode_selection_and_errors(gpu, oracle):
     h = to_host(S, e)
     with pytest.raises(S.capi.SwarmHipError, match="lane_mode"):
         run_gpu(S, h, {"integrator": "hermite", "time_step": "0.001", "lane_mode": "3"}, 0.3)
+
+
+@pytest.mark.parametrize("nbod,nsys", [(3, 200), (5, 77), (8, 40)])
+def test_lane_per_body_ejection_monitor_is_bit_identical(gpu, oracle, nbod, nsys):
+    """stop_on_ejection with deactivate_on_ejection=1 in the lane-per-body kernel: planets on orbits from bound to
+    fast escapers; the step at which each system is disabled (its final time), the flags and every coordinate equal
+    the lane-per-system kernel's and the oracle's stop steps."""
+    S, O = gpu, oracle
+    e = O.generate(nsys, nbod, ejection_factor=2.0)
+    e.vel[:, 1:] *= np.linspace(0.2, 1.0, nsys)[:, None, None]
+    cfg = {"integrator": "hermite", "time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "6"}
+    res = []
+    for mode in (1, 2):
+        h = to_host(S, e)
+        integ = run_gpu(S, h, dict(cfg, lane_mode=str(mode)), 30.0, counters=True)
+        res.append((h, integ.step_counts()[0]))
+    (h1, c1), (h2, c2) = res
+    assert 0 < (h2.state == O.DISABLED).sum() < nsys
+    for k in ("pos", "vel", "time", "state"):
+        assert (getattr(h1, k) == getattr(h2, k)).all(), k
+    assert (c1 == c2).all()
+    o = e.clone()
+    O.integrate(o, O.params("hermite_cpu", 30.0, time_step=0.01), O.monitor(rmax=6.0, deactivate_on_ejection=1), threads=4)
+    assert (h2.state == o.state).all() and (h2.time == o.time).all()
+    # a logging or printing monitor is not served by the lane-per-body kernel: lane_mode=2 falls back, same result
+    h = to_host(S, e)
+    run_gpu(S, h, dict(cfg, lane_mode="2", verbose_on_ejection="1"), 30.0)
+    assert (h.state == h1.state).all() and (h.pos == h1.pos).all()

@@ -27,6 +27,10 @@ WORKLOADS = {
     # Hermite.cfg with the ejection monitor armed (MON_ON variant of the kernel)
     "c2_mon": dict(integrator="hermite", nsys=65536, nbod=3, T=1.0,
                    cfg={"time_step": "0.0001", "deactivate_on_ejection": "1", "rmax": "1000"}),
+    # the close-encounter composite on the fixed-step kernel: evaluated every step
+    "c2_ce": dict(integrator="hermite_cpu_ejection_or_close_encounter", nsys=65536, nbod=3, T=1.0,
+                  cfg={"time_step": "0.0001", "deactivate_on_close_encounter": "1", "close_approach": "0.01",
+                       "deactivate_on_ejection": "1", "rmax": "1000"}),
     # Gauss IRK, test/integrators/irk2.cfg step
     "irk2": dict(integrator="irk2", nsys=65536, nbod=3, T=10.0, cfg={"time_step": "0.01"}),
     "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
