@@ -47,6 +47,16 @@ struct CK {
 //     p_k = pos + h * (c_k * vel + h * sum_j B2[k][j] * k_acc[j]),  B2 = b * b, c_k = rowsum(b[k])
 // which is the same polynomial as the reference's `pos + h*(b[k][0]*k1_vel + ...)` (L158-194)
 // with the products of tableau constants folded at compile time.
+// The monitor proper, out of line.  It is called once per accepted step at most -- six force evaluations apart --
+// and, for stop_on_ejection / log_time_interval, only when the wave-uniform early-out below fails; inlined, its
+// code costs the attempt loop registers (C3: 9.9 ms with the monitor armed against 8.5 ms without).  The state
+// travels through a stack copy so that `s` itself never has its address taken.
+template <int N, bool VERBOSE>
+__device__ __attribute__((noinline)) void rkck_mon_call(MonState *ms, State<N> *s, const MonParams *mp, const LogBuf *lg,
+                                                        bool participate) {
+    mon_call<N, VERBOSE>(*ms, *s, *mp, *lg, participate);
+}
+
 template <int N, bool ADAPTIVE, int MON>
 __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                    Counters cnt) {
@@ -167,7 +177,32 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
             accepted++;
         }
         // monitor runs only for lanes that accepted (L283); the call itself is wave-wide
-        if (MON) mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, accept_step);
+        if (MON != MON_OFF && MON != MON_ON) {
+            mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, accept_step); // printing / every-step monitors: inline
+        } else if (MON) {
+            bool maybe = accept_step;
+            if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
+#pragma clang fp contract(off)
+                maybe = accept_step && mp.log_interval != 0. && s.t >= ms.next_log_time;
+            } else { // stop_on_ejection (the composite with a close-encounter part runs as MON_EVERY_STEP)
+                maybe = false;
+                if (accept_step && mp.ej_any) {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int b = 1; b < N; b++) {
+                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                        maybe = maybe || !(r2 < mp.r2_below);
+                    }
+                }
+            }
+            if (__any(maybe)) {
+                State<N> tmp = s;
+                MonState mtmp = ms;
+                rkck_mon_call<N, false>(&mtmp, &tmp, &mp, &lg, accept_step);
+                s = tmp;
+                ms = mtmp;
+            }
+        }
         if (accept_step && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
     }
     if (accepted || s.state != state_in) store_state(e, gid, s);
@@ -181,7 +216,12 @@ static int launch_n(const LaunchCtx &c) {
     hipLaunchKernelGGL((rkck_kernel<N, ADAPTIVE, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     switch (monitor_variant(c.mp)) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
-    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    case MON_ON:
+        if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any)
+            SWH_LAUNCH_VARIANT(MON_EVERY_STEP);
+        else
+            SWH_LAUNCH_VARIANT(MON_ON);
+        break;
     default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
     }
 #undef SWH_LAUNCH_VARIANT

@@ -19,6 +19,11 @@ WORKLOADS = {
     "c3": dict(integrator="rkck_adaptive", nsys=65536, nbod=6, T=1.0,
                cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27",
                     "deactivate_on_ejection": "1", "rmax": "1000"}),
+    "c3_nomon": dict(integrator="rkck_adaptive", nsys=65536, nbod=6, T=1.0,
+                     cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27"}),
+    "c3_ce": dict(integrator="rkck_adaptive_close_encounter", nsys=65536, nbod=6, T=1.0,
+                  cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27",
+                       "deactivate_on_close_encounter": "1", "close_approach": "0.01"}),
     "c4": dict(integrator="mvs", nsys=131072, nbod=8, T=10.0, cfg={"time_step": "0.01"}),  # one 1/8 shard of 2^20
     # Hermite_Adaptive.cfg + log_time_interval; T=100 (~270 adaptive steps per system), one snapshot
     # per system every 5 time units => 21 records x 288 B x 65536 = 396 MB of log per run
