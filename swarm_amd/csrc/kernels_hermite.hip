@@ -9,6 +9,15 @@
 namespace swh {
 
 
+// The monitor proper, out of line, for the fixed-step kernel with stop_on_ejection or log_time_interval bound
+// (MON_ON): it is reached only when the wave-uniform early-out in the step fails, through a stack copy of the state
+// so that `s` itself never has its address taken.  Inlined, its code costs the two-step loop registers.
+template <int N>
+__device__ __attribute__((noinline)) void hermite_mon_call(MonState *ms, State<N> *s, const MonParams *mp,
+                                                           const LogBuf *lg) {
+    mon_call<N, false>(*ms, *s, *mp, *lg, true);
+}
+
 template <int N, bool ADAPTIVE, int MON>
 __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
@@ -52,7 +61,27 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
             steps++;
             if (MON == MON_TRANSIT)
                 transit_monitor<N>(s, a1, j1, radius, have_radius, mp, lg);
-            else if (MON)
+            else if (MON == MON_ON && !ADAPTIVE) {
+                bool maybe = false;
+                if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
+#pragma clang fp contract(off)
+                    maybe = mp.log_interval != 0. && s.t >= ms.next_log_time;
+                } else if (mp.ej_any) { // stop_on_ejection; the composite with a close-encounter part is MON_EVERY_STEP
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int b = 1; b < N; b++) {
+                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                        maybe = maybe || !(r2 < mp.r2_below);
+                    }
+                }
+                if (__any(maybe)) {
+                    State<N> tmp = s;
+                    MonState mtmp = ms;
+                    hermite_mon_call<N>(&mtmp, &tmp, &mp, &lg);
+                    s = tmp;
+                    ms = mtmp;
+                }
+            } else if (MON)
                 mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
             if (s.state == SWARM_HIP_ACTIVE) {
                 // end test: hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
@@ -126,7 +155,15 @@ static int launch_n(const LaunchCtx &c) {
     hipLaunchKernelGGL((hermite_kernel<N, ADAPTIVE, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     switch (monitor_variant(c.mp)) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
-    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    case MON_ON:
+        if constexpr (!ADAPTIVE) {
+            if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any) {
+                SWH_LAUNCH_VARIANT(MON_EVERY_STEP); // no cheap early-out: the monitor stays inline
+                break;
+            }
+        }
+        SWH_LAUNCH_VARIANT(MON_ON);
+        break;
     case MON_TRANSIT:
         if constexpr (ADAPTIVE) { // plugins/hermite_adap.cu:61 is the only registration of log_transit
             SWH_LAUNCH_VARIANT(MON_TRANSIT);
