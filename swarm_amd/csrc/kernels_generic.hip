@@ -327,6 +327,22 @@ __device__ __forceinline__ double verlet_timestep(const State<N> &s, const IntPa
 }
 
 // ---------------------------------------------------------------------------------------------
+// The monitor of one step, out of line (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
+// standard coordinates only for a system that is about to be logged.  Reached through a stack copy of the state.
+template <int N, int KIND>
+__device__ __attribute__((noinline)) void generic_mon_call(MonState *ms, State<N> *sp, const MonParams *mpp,
+                                                           const LogBuf *lgp) {
+    State<N> &s = *sp;
+    const MonParams &mp = *mpp;
+    const bool needs_std = mon_pass_one<N, false>(*ms, s, mp, *lgp);
+    if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
+    mon_pass_two(*ms, s, mp);
+    const bool want = mon_need_log(*ms, mp);
+    if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
+        if (__any(want)) log_system(*lgp, s, want);
+    if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_internal(s);
+}
+
 // MVS keeps two waves per SIMD (<= 256 registers, a few spilled doubles from nbod 5 on): its Kepler solver is a
 // chain of dependent FP64 operations with quarter-rate reciprocals, and a second resident wave hides them
 // (131072 x 5..8: -15..20 %; at one wave of work per SIMD, 65536 systems, +2..3 %).
@@ -475,7 +491,29 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
 
             // monitor (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
             // standard coordinates only for a system that is about to be logged.
-            if (MON) {
+            if (MON == MON_ON) {
+                // stop_on_ejection / log_time_interval: wave-uniform early-out here, the monitor proper out of line
+                // (generic_mon_call); the close-encounter composite is launched as MON_VERBOSE and stays inline
+                bool maybe = false;
+                if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
+#pragma clang fp contract(off)
+                    maybe = mp.log_interval != 0. && s.t >= ms.next_log_time;
+                } else if (mp.ej_any) {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int b = 1; b < N; b++) {
+                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                        maybe = maybe || !(r2 < mp.r2_below);
+                    }
+                }
+                if (__any(maybe)) {
+                    State<N> tmp = s;
+                    MonState mtmp = ms;
+                    generic_mon_call<N, KIND>(&mtmp, &tmp, &mp, &lg);
+                    s = tmp;
+                    ms = mtmp;
+                }
+            } else if (MON) {
                 const bool needs_std = mon_pass_one<N, MON == MON_VERBOSE>(ms, s, mp, lg);
                 if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
                 mon_pass_two(ms, s, mp);
@@ -500,7 +538,12 @@ static int launch_n(const LaunchCtx &c) {
     hipLaunchKernelGGL((generic_kernel<N, KIND, V>), dim3(c.grid), dim3(c.block), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     switch (monitor_variant(c.mp)) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
-    case MON_ON: SWH_LAUNCH_VARIANT(MON_ON); break;
+    case MON_ON:
+        if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any)
+            SWH_LAUNCH_VARIANT(MON_VERBOSE); // no cheap early-out: inline monitor (prints only if ce_verbose is set)
+        else
+            SWH_LAUNCH_VARIANT(MON_ON);
+        break;
     default: SWH_LAUNCH_VARIANT(MON_VERBOSE); break;
     }
 #undef SWH_LAUNCH_VARIANT

@@ -25,6 +25,8 @@ WORKLOADS = {
                   cfg={"min_time_step": "0.0001", "max_time_step": "0.001", "error_tolerance": "1e-27",
                        "deactivate_on_close_encounter": "1", "close_approach": "0.01"}),
     "c4": dict(integrator="mvs", nsys=131072, nbod=8, T=10.0, cfg={"time_step": "0.01"}),  # one 1/8 shard of 2^20
+    "c4_mon": dict(integrator="mvs", nsys=131072, nbod=8, T=10.0,
+                   cfg={"time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "1000"}),
     # Hermite_Adaptive.cfg + log_time_interval; T=100 (~270 adaptive steps per system), one snapshot
     # per system every 5 time units => 21 records x 288 B x 65536 = 396 MB of log per run
     "c5": dict(integrator="hermite_adap_log", nsys=65536, nbod=4, T=100.0,
