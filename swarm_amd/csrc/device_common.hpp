@@ -679,8 +679,9 @@ __device__ __forceinline__ void transit_monitor(const State<N> &s, const double 
 
 // kernel variant for a launch: 0 = monitor has nothing to do, 1 = monitor, 2 = monitor + lprintf
 //                 3 = mce_stat (kernels_mce.hip, kernels_irk2.hip), 4 = log_transit (hermite_adap_transit)
-// MON_EVERY_STEP (rkck only): a bound monitor without a cheap early-out (the close-encounter composite), kept inline
-enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2, MON_MCE = 3, MON_TRANSIT = 4, MON_EVERY_STEP = 5 };
+// MON_ON: stop_on_ejection / log_time_interval, early-out inline + monitor out of line.  MON_VERBOSE: the monitor
+// inline and lprintf-capable; also used for the close-encounter composite, which has no cheap early-out.
+enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2, MON_MCE = 3, MON_TRANSIT = 4 };
 __host__ __device__ inline bool monitor_is_noop(const MonParams &mp);
 inline int monitor_variant(const MonParams &mp) {
     if (mp.kind == SWARM_HIP_MON_LOG_TRANSIT) return mp.tr_tol != 0. ? MON_TRANSIT : MON_OFF; // is_log_on(), L97

@@ -9,8 +9,7 @@
 namespace swh {
 
 
-// The monitor proper, out of line, for the fixed-step kernel with stop_on_ejection or log_time_interval bound
-// (MON_ON): it is reached only when the wave-uniform early-out in the step fails, through a stack copy of the state
+// The monitor proper, out of line, for the fixed-step kernel with stop_on_ejection or log_time_interval (MON_ON): it is reached only when the wave-uniform early-out in the step fails, through a stack copy of the state
 // so that `s` itself never has its address taken.  Inlined, its code costs the two-step loop registers.
 template <int N>
 __device__ __attribute__((noinline)) void hermite_mon_call(MonState *ms, State<N> *s, const MonParams *mp,
@@ -61,12 +60,12 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
             steps++;
             if (MON == MON_TRANSIT)
                 transit_monitor<N>(s, a1, j1, radius, have_radius, mp, lg);
-            else if (MON == MON_ON && !ADAPTIVE) {
+            else if (MON == MON_ON && !ADAPTIVE) { // adaptive steps differ per lane: some lane's snapshot is due on most steps
                 bool maybe = false;
                 if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
 #pragma clang fp contract(off)
                     maybe = mp.log_interval != 0. && s.t >= ms.next_log_time;
-                } else if (mp.ej_any) { // stop_on_ejection; the composite with a close-encounter part is MON_EVERY_STEP
+                } else if (mp.ej_any) { // stop_on_ejection; the composite with a close-encounter part runs as MON_VERBOSE
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
@@ -156,13 +155,10 @@ static int launch_n(const LaunchCtx &c) {
     switch (monitor_variant(c.mp)) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
     case MON_ON:
-        if constexpr (!ADAPTIVE) {
-            if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any) {
-                SWH_LAUNCH_VARIANT(MON_EVERY_STEP); // no cheap early-out: the monitor stays inline
-                break;
-            }
-        }
-        SWH_LAUNCH_VARIANT(MON_ON);
+        if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any)
+            SWH_LAUNCH_VARIANT(MON_VERBOSE); // no cheap early-out: inline monitor (prints only if ce_verbose is set)
+        else
+            SWH_LAUNCH_VARIANT(MON_ON);
         break;
     case MON_TRANSIT:
         if constexpr (ADAPTIVE) { // plugins/hermite_adap.cu:61 is the only registration of log_transit

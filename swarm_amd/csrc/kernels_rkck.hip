@@ -178,13 +178,13 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
         }
         // monitor runs only for lanes that accepted (L283); the call itself is wave-wide
         if (MON != MON_OFF && MON != MON_ON) {
-            mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, accept_step); // printing / every-step monitors: inline
+            mon_call<N, true>(ms, s, mp, lg, accept_step); // printing / every-step monitors: inline
         } else if (MON) {
             bool maybe = accept_step;
             if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
 #pragma clang fp contract(off)
                 maybe = accept_step && mp.log_interval != 0. && s.t >= ms.next_log_time;
-            } else { // stop_on_ejection (the composite with a close-encounter part runs as MON_EVERY_STEP)
+            } else { // stop_on_ejection (the composite with a close-encounter part runs as MON_VERBOSE)
                 maybe = false;
                 if (accept_step && mp.ej_any) {
 #pragma clang fp contract(off)
@@ -218,7 +218,7 @@ static int launch_n(const LaunchCtx &c) {
     case MON_OFF: SWH_LAUNCH_VARIANT(MON_OFF); break;
     case MON_ON:
         if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any)
-            SWH_LAUNCH_VARIANT(MON_EVERY_STEP);
+            SWH_LAUNCH_VARIANT(MON_VERBOSE); // no cheap early-out: inline monitor (prints only if ce_verbose is set)
         else
             SWH_LAUNCH_VARIANT(MON_ON);
         break;
