@@ -454,6 +454,23 @@ __device__ __forceinline__ bool ej_test_body(const State<N> &s, int b, const Mon
     return false;
 }
 
+// test_body without the verbose branch, on one body's scalars; same operations as ej_test_body
+__device__ __forceinline__ bool ej_test_quiet(const double (&p)[3], const double (&v)[3], const double m,
+                                              const MonParams &mp) {
+#pragma clang fp contract(off)
+    const double x = p[0], y = p[1], z = p[2];
+    const double r2 = x * x + y * y + z * z;
+    if (r2 < mp.r2_below) return false;
+    const double vx = v[0], vy = v[1], vz = v[2];
+    const double r = sqrt(r2);
+    if (r < mp.rmax) return false;
+    const double rdotv = x * vx + y * vy + z * vz;
+    if (rdotv <= 0.) return false;
+    const double speed_sq = vx * vx + vy * vy + vz * vz;
+    const double epp = 0.5 * speed_sq * r / m - 1.;
+    return fabs(epp) < 1e-4 || epp > 0;
+}
+
 // stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142
 template <int N, bool VERBOSE>
 __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp, const LogBuf &lg) {
@@ -681,7 +698,8 @@ __device__ __forceinline__ void transit_monitor(const State<N> &s, const double 
 //                 3 = mce_stat (kernels_mce.hip, kernels_irk2.hip), 4 = log_transit (hermite_adap_transit)
 // MON_ON: stop_on_ejection / log_time_interval, early-out inline + monitor out of line.  MON_VERBOSE: the monitor
 // inline and lprintf-capable; also used for the close-encounter composite, which has no cheap early-out.
-enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2, MON_MCE = 3, MON_TRANSIT = 4 };
+// MON_EJECT_QUIET (fixed-step hermite): stop_on_ejection with nothing to log or print -- the test alone, inline.
+enum { MON_OFF = 0, MON_ON = 1, MON_VERBOSE = 2, MON_MCE = 3, MON_TRANSIT = 4, MON_EJECT_QUIET = 5 };
 __host__ __device__ inline bool monitor_is_noop(const MonParams &mp);
 inline int monitor_variant(const MonParams &mp) {
     if (mp.kind == SWARM_HIP_MON_LOG_TRANSIT) return mp.tr_tol != 0. ? MON_TRANSIT : MON_OFF; // is_log_on(), L97

@@ -60,7 +60,24 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
             steps++;
             if (MON == MON_TRANSIT)
                 transit_monitor<N>(s, a1, j1, radius, have_radius, mp, lg);
-            else if (MON == MON_ON && !ADAPTIVE) { // adaptive steps differ per lane: some lane's snapshot is due on most steps
+            else if (MON == MON_EJECT_QUIET) {
+                // stop_on_ejection, deactivation only: early-out, then the bare test (no records, no printf, no call)
+                bool maybe = false;
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int b = 1; b < N; b++) {
+                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
+                        maybe = maybe || !(r2 < mp.r2_below);
+                    }
+                }
+                if (__any(maybe)) {
+                    bool met = false;
+#pragma unroll
+                    for (int b = 1; b < N; b++) met = met || ej_test_quiet(s.p[b], s.v[b], s.m[b], mp);
+                    if (met && mp.ej_deactivate) s.state = SWARM_HIP_DISABLED;
+                }
+            } else if (MON == MON_ON && !ADAPTIVE) { // adaptive steps differ per lane: some lane's snapshot is due on most steps
                 bool maybe = false;
                 if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
 #pragma clang fp contract(off)
@@ -157,7 +174,9 @@ static int launch_n(const LaunchCtx &c) {
     case MON_ON:
         if (c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE && c.mp.ce_any)
             SWH_LAUNCH_VARIANT(MON_VERBOSE); // no cheap early-out: inline monitor (prints only if ce_verbose is set)
-        else
+        else if (!ADAPTIVE && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log) {
+            if constexpr (!ADAPTIVE) SWH_LAUNCH_VARIANT(MON_EJECT_QUIET);
+        } else
             SWH_LAUNCH_VARIANT(MON_ON);
         break;
     case MON_TRANSIT:

@@ -19,23 +19,6 @@
 
 namespace swh {
 
-// test_body without the verbose branch; same operations as ej_test_body (device_common.hpp)
-__device__ __forceinline__ bool ej_test_quiet(const double (&p)[3], const double (&v)[3], const double m,
-                                              const MonParams &mp) {
-#pragma clang fp contract(off)
-    const double x = p[0], y = p[1], z = p[2];
-    const double r2 = x * x + y * y + z * z;
-    if (r2 < mp.r2_below) return false;
-    const double vx = v[0], vy = v[1], vz = v[2];
-    const double r = sqrt(r2);
-    if (r < mp.rmax) return false;
-    const double rdotv = x * vx + y * vy + z * vz;
-    if (rdotv <= 0.) return false;
-    const double speed_sq = vx * vx + vy * vy + vz * vz;
-    const double epp = 0.5 * speed_sq * r / m - 1.;
-    return fabs(epp) < 1e-4 || epp > 0;
-}
-
 template <int N, bool EJ>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
