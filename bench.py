@@ -188,7 +188,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                      # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE doubled per
                      # the MI355X guide + WRITE_SIZE), profiles/r1/hermite_n3_pmc.json; algorithmic = 340 B/system
-                     "traffic": 22212279 if (nbod, nsys) == (3, 65536) else None,
+                     "traffic": 22216997 if (nbod, nsys) == (3, 65536) else None,
                      "kernel": "hermite_kernel<%d,false,0>" % nbod,
                      "kernel_ms_avg": kernel_ms_avg,
                      "flop_per_system_step": flops,
