@@ -138,12 +138,14 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
                 double tf = 0.0;
 #pragma unroll
                 for (int b = 0; b < N; b++) {
-                    const double a2 = fa[0][b][0] * fa[0][b][0] + fa[0][b][1] * fa[0][b][1] + fa[0][b][2] * fa[0][b][2];
-                    const double jj = fj[0][b][0] * fj[0][b][0] + fj[0][b][1] * fj[0][b][1] + fj[0][b][2] * fj[0][b][2];
-                    const double ratio = fdiv(jj, a2);
-                    tf = (b == 0) ? ratio : tf + ratio;
+                    // (explicit fused form: what the compiler's contraction gives, fixed so that the lane-per-body
+                    // kernel computes the same bits)
+                    const double a2 = __builtin_fma(fa[0][b][2], fa[0][b][2], __builtin_fma(fa[0][b][1], fa[0][b][1], fa[0][b][0] * fa[0][b][0]));
+                    const double jj = __builtin_fma(fj[0][b][2], fj[0][b][2], __builtin_fma(fj[0][b][1], fj[0][b][1], fj[0][b][0] * fj[0][b][0]));
+                    const double ra = rcp_full(a2); // jj / a2 through the reciprocal, fused into the running sum
+                    tf = (b == 0) ? jj * ra : __builtin_fma(jj, ra, tf);
                 }
-                h = rsqrt_full(tf) * ip.time_step_factor + ip.min_time_step;
+                h = __builtin_fma(rsqrt_full(tf), ip.time_step_factor, ip.min_time_step);
             } else {
                 h = ip.time_step;
             }
@@ -202,14 +204,14 @@ static bool small_ensemble(const LaunchCtx &c) {
 }
 
 int launch_hermite(const LaunchCtx &c, bool adaptive) {
+    // small ensembles with nothing to monitor, or only stop_on_ejection's deactivation (no records, no printf):
+    // one lane per body (kernels_hermite_body.hip), each lane testing its own planet
+    const int variant = monitor_variant(c.mp);
+    const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
+    if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {
-        // small ensembles with nothing to monitor: one lane per body (kernels_hermite_body.hip)
-        // ... or only stop_on_ejection's deactivation (no records, no printf): each lane tests its own planet
-        const int variant = monitor_variant(c.mp);
-        const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
-        if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, false>(c)));
     }
     return SWARM_HIP_OK;

@@ -1,4 +1,4 @@
-// kernels_hermite_body.hip -- fixed-step PEC2 Hermite with ONE LANE PER BODY, for small ensembles.
+// kernels_hermite_body.hip -- PEC2 Hermite (fixed and adaptive step) with ONE LANE PER BODY, for small ensembles.
 //
 // The one-lane-per-system kernel (kernels_hermite.hip) needs >= 65536 systems to put one wavefront
 // on every SIMD; below that its run time is the latency of one wave's dependent steps whatever nsys
@@ -19,7 +19,7 @@
 
 namespace swh {
 
-template <int N, bool EJ>
+template <int N, bool EJ, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     const int lane = threadIdx.x;
@@ -51,6 +51,14 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
         state = e.sysi[chunk * 2 * W + sl];
     }
     const int state_in = state;
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    auto ejection_monitor = [&](const bool take_part) {
+        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+        const bool met = (__ballot(ej) & group_mask) != 0;
+        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+    };
+    // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
+    if (EJ && ADAPTIVE) ejection_monitor(valid);
 
     // forces on my body from the current p, v of all lanes; wave-wide (shuffles), no divergence inside
     auto forces = [&](double (&a)[3], double (&jk)[3]) {
@@ -90,11 +98,24 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     // lanes of finished or idle groups compute and discard.
     while (__any(active)) {
         double h = ip.time_step;
+        if (ADAPTIVE) {
+            // calc_adaptive_time_step, hermite_adap.hpp:69-98: |jerk|^2/|acc|^2 summed over the bodies in index order
+            const double a2 = __builtin_fma(a0[2], a0[2], __builtin_fma(a0[1], a0[1], a0[0] * a0[0]));
+            const double jj = __builtin_fma(j0[2], j0[2], __builtin_fma(j0[1], j0[1], j0[0] * j0[0]));
+            const double ra = rcp_full(a2);
+            double tf = __shfl(jj, base) * __shfl(ra, base);
+#pragma unroll
+            for (int j = 1; j < N; j++) tf = __builtin_fma(__shfl(jj, base + j), __shfl(ra, base + j), tf);
+            h = __builtin_fma(rsqrt_full(tf), ip.time_step_factor, ip.min_time_step);
+        }
         {
 #pragma clang fp contract(off)
             if (t + h > dest) h = dest - t; // hermite_integrator.hpp:120-123
         }
-        if (h != k.h) k.set(h);
+        if (ADAPTIVE)
+            k.template set<true>(h);
+        else if (h != k.h)
+            k.set(h);
         const double p_in[3] = {p[0], p[1], p[2]}, v_in[3] = {v[0], v[1], v[2]};
         double pp[3], pv[3], c0[3], dd0[3];
 #pragma unroll
@@ -124,15 +145,12 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             steps++;
             iter++;
         }
-        if (EJ) { // stop_on_ejection::operator(), after the step and before the end-of-integration test
-            const bool ej = active && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-            const bool met = (__ballot(ej) & group_mask) != 0;
-            if (active && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-        }
+        if (EJ) ejection_monitor(active); // after the step and before the end-of-integration test
         if (active) {
             if (state == SWARM_HIP_ACTIVE) {
 #pragma clang fp contract(off)
-                if (t > dest - 1e-12) state = SWARM_HIP_INACTIVE; // hermite_integrator.hpp:177-179
+                // hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
+                if (ADAPTIVE ? (t >= dest) : (t > dest - 1e-12)) state = SWARM_HIP_INACTIVE;
             }
             active = state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
         } else { // a finished system keeps its state while the rest of the wave goes on
@@ -158,16 +176,31 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
 }
 
 // one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
-int launch_hermite_body(const LaunchCtx &c) {
-    SWH_DISPATCH_NBOD(c.ens.nbod, {
-        constexpr int G = W / N;
-        const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-        if (monitor_variant(c.mp) == MON_OFF)
-            hipLaunchKernelGGL((hermite_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+template <int N>
+static int launch_body_n(const LaunchCtx &c, bool adaptive) {
+    constexpr int G = W / N;
+    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    const bool ej = monitor_variant(c.mp) != MON_OFF;
+#define SWH_LAUNCH_BODY(EJ, AD) \
+    hipLaunchKernelGGL((hermite_body_kernel<N, EJ, AD>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt)
+    if (adaptive) {
+        if (ej)
+            SWH_LAUNCH_BODY(true, true);
         else
-            hipLaunchKernelGGL((hermite_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
-    });
+            SWH_LAUNCH_BODY(false, true);
+    } else {
+        if (ej)
+            SWH_LAUNCH_BODY(true, false);
+        else
+            SWH_LAUNCH_BODY(false, false);
+    }
+#undef SWH_LAUNCH_BODY
     return check_launch("hermite (lane per body) kernel launch");
+}
+
+int launch_hermite_body(const LaunchCtx &c, bool adaptive) {
+    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N>(c, adaptive)));
+    return SWARM_HIP_OK;
 }
 
 } // namespace swh

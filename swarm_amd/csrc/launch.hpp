@@ -22,7 +22,7 @@ void set_error(const char *fmt, ...);
 
 // one entry per kernel translation unit; each dispatches on nbod
 int launch_hermite(const LaunchCtx &c, bool adaptive);
-int launch_hermite_body(const LaunchCtx &c); // one lane per body, small ensembles (kernels_hermite_body.hip)
+int launch_hermite_body(const LaunchCtx &c, bool adaptive); // one lane per body, small ensembles (kernels_hermite_body.hip)
 int launch_hermite_mce(const LaunchCtx &c); // `hermite` + mce_stat (plugins/hermite.cu:40)
 int launch_rkck(const LaunchCtx &c, bool adaptive);
 int launch_generic(const LaunchCtx &c, int integrator);

@@ -257,3 +257,59 @@ def test_lane_per_body_ejection_monitor_is_bit_identical(gpu, oracle, nbod, nsys
     h = to_host(S, e)
     run_gpu(S, h, dict(cfg, lane_mode="2", verbose_on_ejection="1"), 30.0)
     assert (h.state == h1.state).all() and (h.pos == h1.pos).all()
+
+
+@pytest.mark.parametrize("nbod,nsys", [(3, 300), (4, 128), (6, 45), (9, 10)])
+def test_lane_per_body_adaptive_is_bit_identical(gpu, oracle, nbod, nsys):
+    """hermite_adap through the lane-per-body kernel: the per-system step is the ordered sum of the bodies'
+    |jerk|^2/|acc|^2, gathered from the lanes of the system; steps taken, final times and every coordinate equal the
+    lane-per-system kernel's, for own start times, mixed states and an iteration budget that splits the run."""
+    S, O = gpu, oracle
+    e = perturbed(O, nsys, nbod, seed=200 + nbod)
+    e.time[:] = np.linspace(0.0, 1.5, nsys)
+    e.state[4::9] = O.DISABLED
+    cfg = {"integrator": "hermite_adap", "time_step_factor": "0.017", "min_time_step": "1e-5"}
+    res = []
+    for mode in (1, 2):
+        h = to_host(S, e)
+        integ = run_gpu(S, h, dict(cfg, lane_mode=str(mode)), 40.0, counters=True)
+        res.append((h, integ.step_counts()[0]))
+    (h1, c1), (h2, c2) = res
+    assert (c1 == c2).all() and c1.max() > 50
+    for k in ("pos", "vel", "time", "state"):
+        assert (getattr(h1, k) == getattr(h2, k)).all(), k
+    # an iteration budget splits the run into launches; a launch starts from forces evaluated at the stored state
+    # (the carried ones belong to the once-corrected positions), so the split run is compared between the kernels
+    split = []
+    for mode in (1, 2):
+        h = to_host(S, e)
+        integ = S.Integrator.create(S.config(dict(cfg, lane_mode=str(mode), max_iterations="40")))
+        integ.set_ensemble(h)
+        integ.set_destination_time(40.0)
+        assert integ.integrate() > 1
+        split.append(h)
+    assert (split[0].pos == split[1].pos).all() and (split[0].time == split[1].time).all()
+    assert (split[0].state == split[1].state).all()
+    o = e.clone()
+    O.integrate(o, O.params("hermite_adap", 40.0, time_step_factor=0.017, min_time_step=1e-5), threads=4)
+    assert rel_diff(h2.pos[:, 1:], o.pos[:, 1:]) < 1e-9 and (h2.state == o.state).all()
+
+
+def test_lane_per_body_adaptive_with_ejection_fixture(gpu, oracle):
+    """test/monitors/hyperbolic_orbits/HermiteEjection.cfg (hermite_adap, deactivate_on_ejection=1, rmax=20) on its
+    128 systems selects the lane-per-body kernel by itself; forced either way the outcome is the same bits, and it is
+    the reference's: all 128 systems disabled at t ~ 8."""
+    S, O = gpu, oracle
+    d = os.path.join(GOLDEN, "monitors", "hyperbolic_orbits")
+    e = O.load_text(os.path.join(d, "3.in.txt"))
+    ref = O.load_text(os.path.join(d, "HermiteEjection.3.out.txt"))
+    cfg = dict(S.config.load(os.path.join(d, "HermiteEjection.cfg")))
+    out = []
+    for mode in ("0", "1", "2"):
+        h = to_host(S, e)
+        run_gpu(S, h, dict(cfg, lane_mode=mode), float(cfg["destination_time"]))
+        out.append(h)
+    for h in out[1:]:
+        assert (h.pos == out[0].pos).all() and (h.time == out[0].time).all() and (h.state == out[0].state).all()
+    assert (out[0].state == ref.state).all() and (ref.state == O.DISABLED).all()
+    np.testing.assert_allclose(out[0].time, ref.time, atol=5e-3)
