@@ -5,6 +5,7 @@
 // lives in that lane's VGPRs for every step of the launch, so the reference's per-step global
 // round trips, shared-memory pair tables and __syncthreads (swarm/gpu/gravitation_accjerk.hpp:186-197,
 // SURVEY 3.3) disappear.  HBM is touched once per launch: coalesced 512-byte rows per field.
+// (Small ensembles of hermite / hermite_adap: one lane per BODY instead, kernels_hermite_body.hip, same bits.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -555,8 +556,9 @@ __device__ __forceinline__ bool mon_need_log(const MonState &ms, const MonParams
 }
 
 // Monitor::operator()(thread_in_system): pass_one, pass_two, log (stop_on_ejection.hpp:140-146).
-// `participate` = this lane really calls the monitor; all lanes of the wave must reach this
-// function together because log_system reserves space wave-wide.
+// `participate` = this lane really calls the monitor.  The lanes that reach this function together
+// (the whole wave in rkck, the lanes still integrating elsewhere) reserve log space together: the
+// ballots inside see exactly the lanes that are here.
 template <int N, bool VERBOSE>
 __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonParams &mp,
                                          const LogBuf &lg, bool participate) {
