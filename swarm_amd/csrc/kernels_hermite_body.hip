@@ -138,24 +138,29 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
                 v[c] = pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
             }
         }
+        auto end_test = [&]() {
+            if (state == SWARM_HIP_ACTIVE) {
+                // hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
+#pragma clang fp contract(off)
+                if (ADAPTIVE ? (t >= dest) : (t > dest - 1e-12)) state = SWARM_HIP_INACTIVE;
+            }
+            active = state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
+        };
+        const bool stepped = active;
         if (active) {
 #pragma unroll
             for (int c = 0; c < 3; c++) a0[c] = a1[c], j0[c] = j1[c];
             t += h;
             steps++;
             iter++;
-        }
-        if (EJ) ejection_monitor(active); // after the step and before the end-of-integration test
-        if (active) {
-            if (state == SWARM_HIP_ACTIVE) {
-#pragma clang fp contract(off)
-                // hermite_integrator.hpp:177-179 (`>` dest-1e-12), hermite_adap.hpp:191-193 (`>=`)
-                if (ADAPTIVE ? (t >= dest) : (t > dest - 1e-12)) state = SWARM_HIP_INACTIVE;
-            }
-            active = state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
+            if (!EJ) end_test(); // one divergent region per step when there is nothing to monitor
         } else { // a finished system keeps its state while the rest of the wave goes on
 #pragma unroll
             for (int c = 0; c < 3; c++) p[c] = p_in[c], v[c] = v_in[c];
+        }
+        if (EJ) { // stop_on_ejection::operator(): after the step, before the end-of-integration test; wave-wide ballot
+            ejection_monitor(stepped);
+            if (stepped) end_test();
         }
     }
     if (valid && (steps || state != state_in)) {
