@@ -63,7 +63,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.rehearse_one_gpu else dev   # where collective operands live
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # under torchrun the exchange runs even with one rank (RCCL rehearsal)
         import torch.distributed as dist
         if args.rehearse_one_gpu:
             dist.init_process_group("gloo")
