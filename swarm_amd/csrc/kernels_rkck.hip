@@ -153,17 +153,25 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
             const float step_grow_max_factor = 5.0;
             const float step_shrink_min_factor = 0.2;
             const double normalized_error = max_error / ip.error_tolerance;
-            const double step_guess_power = (normalized_error < 1.) ? step_grow_power : step_shrink_power;
-            const double step_change_factor =
-                ((normalized_error < 0.5) || (normalized_error > 1.0))
-                    ? step_guess_safety_factor * pow(normalized_error, 0.5 * step_guess_power)
-                    : 1.0;
-            const double new_time_step =
-                (normalized_error > 1.)
-                    ? fmax(time_step * fmax(step_change_factor, (double)step_shrink_min_factor),
-                           ip.min_time_step)
-                    : fmin(time_step * fmax(fmin(step_change_factor, (double)step_grow_max_factor), 1.0),
-                           ip.max_time_step);
+            // Cruising at the cap: for normalized_error < 0.25 the grow factor 0.9f * pow(e, -0.0833..) lies in
+            // [1.0102, inf] (e = 0 gives inf, clamped to 5), so time_step * factor >= time_step * 1.01 and, once
+            // that reaches max_time_step, the fmin below returns max_time_step whatever pow() says: the same value
+            // without the 226 instructions of pow().  Waves whose lanes all cruise skip them (C3: every step).
+            const bool capped = (normalized_error < 0.25) && (time_step * 1.01 >= ip.max_time_step);
+            double new_time_step = ip.max_time_step;
+            if (!capped) {
+                const double step_guess_power = (normalized_error < 1.) ? step_grow_power : step_shrink_power;
+                const double step_change_factor =
+                    ((normalized_error < 0.5) || (normalized_error > 1.0))
+                        ? step_guess_safety_factor * pow(normalized_error, 0.5 * step_guess_power)
+                        : 1.0;
+                new_time_step =
+                    (normalized_error > 1.)
+                        ? fmax(time_step * fmax(step_change_factor, (double)step_shrink_min_factor),
+                               ip.min_time_step)
+                        : fmin(time_step * fmax(fmin(step_change_factor, (double)step_grow_max_factor), 1.0),
+                               ip.max_time_step);
+            }
             accept_step = (normalized_error < 1.0) || (fabs(time_step - new_time_step) < 1e-10);
             time_step = new_time_step;
         }
