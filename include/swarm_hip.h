@@ -184,7 +184,9 @@ int swarm_hip_import_ref_layout(const swarm_hip_ensemble_t *ens, const void *d_r
 int swarm_hip_export_ref_layout(const swarm_hip_ensemble_t *ens, void *d_ref_body, void *d_ref_sys,
                                 int32_t ref_chunk, void *stream);
 
-/* Plain host AoS arrays <-> device wave chunks (synchronous; stages through a host buffer).
+/* Plain host AoS arrays <-> device wave chunks (synchronous; the arrays are copied as they are into a
+ * device staging buffer and transposed on the GPU.  Each device keeps its staging buffer between calls,
+ * grow-only, for ensembles up to 1 GiB; calls that overlap on one GPU are serialised).
  * pos/vel [nsys][nbod][3], mass [nsys][nbod], time [nsys], state/id [nsys],
  * body_attr [nsys][nbod][nbattr] (may be NULL), sys_attr [nsys][nsattr] (may be NULL).
  * = alloc_copy H2D/D2H (swarm/types/allocators.hpp:152-166) for callers without the

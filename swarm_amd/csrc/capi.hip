@@ -268,11 +268,41 @@ struct AosStage {
     double *pos, *vel, *mass, *time, *battr, *sattr;
     int32_t *state, *id;
     void *base;
+    bool owned; // false: the device's kept staging buffer
 };
-static int aos_stage_alloc(const swarm_hip_ensemble_t *ens, AosStage &st) {
+// The staging buffer of a device is kept between calls (grow-only, up to STAGE_KEEP_MAX; larger requests are
+// private to their call): the reference pays a cudaMalloc/cudaFree pair per transfer (types/allocators.hpp:152-166),
+// which for a 14..70 MB ensemble costs as much as the copy itself.  A call holds the device's staging mutex from
+// aos_stage_alloc to its return, so transfers that overlap on one GPU run one after the other.
+constexpr size_t STAGE_KEEP_MAX = (size_t)1 << 30;
+struct StageCache {
+    std::mutex mu;
+    void *base = nullptr;
+    size_t bytes = 0;
+};
+static StageCache g_stage[MAX_DEV];
+
+static int aos_stage_alloc(const swarm_hip_ensemble_t *ens, AosStage &st, std::unique_lock<std::mutex> &hold) {
     const size_t nsys = ens->nsys, n = ens->nbod;
     const size_t nd = nsys * n * 3 * 2 + nsys * n + nsys + nsys * n * ens->nbattr + nsys * ens->nsattr;
-    HIP_TRY(hipMalloc(&st.base, nd * sizeof(double) + 2 * nsys * sizeof(int32_t) + 64));
+    const size_t bytes = nd * sizeof(double) + 2 * nsys * sizeof(int32_t) + 64;
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    st.owned = true;
+    if (dev >= 0 && dev < MAX_DEV && bytes <= STAGE_KEEP_MAX) {
+        StageCache &c = g_stage[dev];
+        hold = std::unique_lock<std::mutex>(c.mu);
+        if (c.bytes < bytes) {
+            if (c.base) (void)hipFree(c.base);
+            c.base = nullptr, c.bytes = 0;
+            HIP_TRY(hipMalloc(&c.base, bytes));
+            c.bytes = bytes;
+        }
+        st.base = c.base;
+        st.owned = false;
+    } else {
+        HIP_TRY(hipMalloc(&st.base, bytes));
+    }
     double *p = (double *)st.base;
     st.pos = p, p += nsys * n * 3;
     st.vel = p, p += nsys * n * 3;
@@ -283,6 +313,10 @@ static int aos_stage_alloc(const swarm_hip_ensemble_t *ens, AosStage &st) {
     st.state = (int32_t *)p;
     st.id = st.state + nsys;
     return SWARM_HIP_OK;
+}
+static void aos_stage_release(AosStage &st) {
+    if (st.owned && st.base) (void)hipFree(st.base);
+    st.base = nullptr;
 }
 
 // to_chunks: AoS staging -> wave chunks (padding lanes: DISABLED, id -1, zeros); else the reverse
@@ -612,7 +646,8 @@ int swarm_hip_upload_aos(const swarm_hip_ensemble_t *ens, const double *pos, con
     if (ens->nsys == 0) return SWARM_HIP_OK;
     const size_t nsys = ens->nsys, n = ens->nbod;
     AosStage st;
-    rc = aos_stage_alloc(ens, st);
+    std::unique_lock<std::mutex> hold;
+    rc = aos_stage_alloc(ens, st, hold);
     if (rc) return rc;
     hipError_t err = hipSuccess;
     auto h2d = [&](void *d, const void *h, size_t bytes) {
@@ -633,7 +668,7 @@ int swarm_hip_upload_aos(const swarm_hip_ensemble_t *ens, const double *pos, con
         err = hipGetLastError();
         if (err == hipSuccess) err = hipDeviceSynchronize();
     }
-    (void)hipFree(st.base);
+    aos_stage_release(st);
     HIP_TRY(err);
     return SWARM_HIP_OK;
 }
@@ -645,7 +680,8 @@ int swarm_hip_download_aos(const swarm_hip_ensemble_t *ens, double *pos, double 
     if (ens->nsys == 0) return SWARM_HIP_OK;
     const size_t nsys = ens->nsys, n = ens->nbod;
     AosStage st;
-    rc = aos_stage_alloc(ens, st);
+    std::unique_lock<std::mutex> hold;
+    rc = aos_stage_alloc(ens, st, hold);
     if (rc) return rc;
     const size_t nlanes = (size_t)swarm_hip_nchunk(ens->nsys) * W;
     hipLaunchKernelGGL((aos_convert_kernel<false>), dim3((unsigned)((nlanes + 255) / 256)), dim3(256), 0, 0, view_of(ens), st,
@@ -663,7 +699,7 @@ int swarm_hip_download_aos(const swarm_hip_ensemble_t *ens, double *pos, double 
     d2h(state, st.state, nsys * sizeof(int32_t));
     d2h(id, st.id, nsys * sizeof(int32_t));
     if (err == hipSuccess) err = hipDeviceSynchronize();
-    (void)hipFree(st.base);
+    aos_stage_release(st);
     HIP_TRY(err);
     return SWARM_HIP_OK;
 }

@@ -5,6 +5,7 @@ DeviceEnsemble owns the wave-chunk device image (include/swarm_hip.h) -- the cou
 deviceEnsemble / EnsembleAlloc::cloneTo (swarm/ensemble_alloc.hpp:30-68)."""
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -13,26 +14,61 @@ from . import capi
 FLT_MAX = float(np.finfo(np.float32).max)
 
 
+def _free_pinned(ptr):
+    try:
+        capi.lib.swarm_hip_host_free(C.c_void_p(ptr))
+    except Exception:       # interpreter shutdown
+        pass
+
+
+def _pinned_block(nbytes):
+    """page-locked host memory (hipHostMalloc) as a ctypes buffer; freed when the last numpy view of it dies"""
+    p = C.c_void_p()
+    capi.check(capi.lib.swarm_hip_host_alloc(C.byref(p), C.c_size_t(nbytes)))
+    buf = (C.c_uint8 * nbytes).from_address(p.value)
+    weakref.finalize(buf, _free_pinned, p.value)
+    return buf
+
+
 class HostEnsemble:
-    def __init__(self, nsys, nbod, nbattr=1, nsattr=1):
+    """pinned=True is swarm::hostEnsemble (HostAllocator = cudaMallocHost, types/allocators.hpp:93-110,
+    ensemble_alloc.hpp:66): the arrays live in one page-locked block, so upload/download run as DMA at PCIe
+    speed; the default is defaultEnsemble (plain pageable memory)."""
+
+    FIELDS = ("pos", "vel", "mass", "time", "body_attr", "sys_attr", "state", "id")
+
+    def __init__(self, nsys, nbod, nbattr=1, nsattr=1, pinned=False):
         self.nsys, self.nbod, self.nbattr, self.nsattr = int(nsys), int(nbod), int(nbattr), int(nsattr)
-        self.pos = np.zeros((nsys, nbod, 3))
-        self.vel = np.zeros((nsys, nbod, 3))
-        self.mass = np.zeros((nsys, nbod))
-        self.time = np.zeros(nsys)
-        self.state = np.zeros(nsys, dtype=np.int32)
-        self.id = np.arange(nsys, dtype=np.int32)
-        self.body_attr = np.zeros((nsys, nbod, nbattr))
-        self.sys_attr = np.zeros((nsys, nsattr))
+        self.pinned = bool(pinned)
+        shapes = {"pos": (nsys, nbod, 3), "vel": (nsys, nbod, 3), "mass": (nsys, nbod), "time": (nsys,),
+                  "body_attr": (nsys, nbod, nbattr), "sys_attr": (nsys, nsattr), "state": (nsys,), "id": (nsys,)}
+        if pinned:
+            sizes = {k: int(np.prod(shapes[k])) * (4 if k in ("state", "id") else 8) for k in self.FIELDS}
+            buf = _pinned_block(sum(sizes.values()) + 64)
+            off = 0
+            for k in self.FIELDS:       # doubles first, so every array is 8-byte aligned
+                dt = np.int32 if k in ("state", "id") else np.float64
+                a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shapes[k])), offset=off).reshape(shapes[k])
+                a[...] = 0
+                setattr(self, k, a)
+                off += sizes[k]
+        else:
+            for k in self.FIELDS:
+                setattr(self, k, np.zeros(shapes[k], dtype=np.int32 if k in ("state", "id") else np.float64))
+        self.id[:] = np.arange(nsys, dtype=np.int32)
 
     @staticmethod
     def create(nbod, nsys):
         return HostEnsemble(nsys, nbod)
 
-    def clone(self):
-        e = HostEnsemble(self.nsys, self.nbod, self.nbattr, self.nsattr)
-        for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
-            setattr(e, k, getattr(self, k).copy())
+    def clone(self, pinned=None):
+        pinned = self.pinned if pinned is None else pinned
+        e = HostEnsemble(self.nsys, self.nbod, self.nbattr, self.nsattr, pinned=pinned)
+        for k in self.FIELDS:
+            if pinned:
+                getattr(e, k)[...] = getattr(self, k)
+            else:
+                setattr(e, k, getattr(self, k).copy())
         return e
 
     def slice(self, lo, hi):

@@ -54,6 +54,36 @@ def test_upload_download_roundtrip(gpu, oracle, nsys, nbod):
     np.testing.assert_array_equal(en, O.total_energy(e))      # same operation order, no FMA: bit-exact
 
 
+def test_pinned_host_ensemble_and_kept_staging_buffer(gpu, oracle):
+    """hostEnsemble (page-locked, types/allocators.hpp:93-110): same bytes through upload / integrate / download as
+    the pageable defaultEnsemble; its arrays outlive the ensemble object.  The calls go large -> small -> large so
+    that the device's kept staging buffer is reused at a smaller size and then regrown."""
+    S, O = gpu, oracle
+    outs = []
+    for nsys, nbod in [(3000, 6), (70, 3), (5000, 8)]:
+        e = perturbed(O, nsys, nbod, seed=7)
+        e.sys_attr[:] = np.arange(nsys)[:, None] * 0.25
+        plain = to_host(S, e)
+        pinned = plain.clone(pinned=True)
+        assert pinned.pinned and not plain.pinned
+        for k in S.HostEnsemble.FIELDS:
+            assert (getattr(pinned, k) == getattr(plain, k)).all(), k
+        for h in (plain, pinned):
+            integ = S.Integrator.create(S.config({"integrator": "hermite", "time_step": "1e-3"}))
+            integ.set_ensemble(h)
+            integ.set_destination_time(0.05)
+            integ.integrate()
+        for k in S.HostEnsemble.FIELDS:
+            assert (getattr(pinned, k) == getattr(plain, k)).all(), k
+        assert (pinned.time == 0.05).all()
+        outs.append((pinned.pos, plain.pos.copy()))
+        del pinned
+    import gc
+    gc.collect()
+    for a, b in outs:       # views keep the page-locked block alive
+        assert (a == b).all()
+
+
 @pytest.mark.parametrize("RC", [4, 8, 16, 64])
 @pytest.mark.parametrize("nsys,nbod", [(8, 3), (100, 3), (777, 5), (2048, 8)])
 def test_reference_layout_import_export(gpu, oracle, RC, nsys, nbod):
