@@ -367,6 +367,80 @@ __global__ __launch_bounds__(256) void aos_convert_kernel(EnsView e, AosStage st
 }
 
 
+// The same conversion with the transposition staged through LDS: one workgroup per wave chunk.  A chunk's AoS data
+// is a contiguous run of 64*F doubles per field group (F = 3n for pos and vel, n for mass, n*nbattr for the body
+// attributes), read or written with consecutive lanes on consecutive doubles; the device side is whole 512-byte rows.
+// The tile is [64][F|1]: an odd row stride keeps the column accesses free of bank conflicts.  The system data
+// (time, attributes, state, id) are per-lane streams already and go through the first wavefront.
+template <bool TO_CHUNKS>
+__global__ __launch_bounds__(256) void aos_tile_kernel(EnsView e, AosStage st, bool have_battr, bool have_sattr) {
+    extern __shared__ double tile[];
+    const size_t k = blockIdx.x, s0 = k * W;
+    const int t = threadIdx.x, n = e.nbod, nba = e.nbf - 7, nsa = e.nsf - 1;
+    const int r = (size_t)e.nsys - s0 < (size_t)W ? (int)((size_t)e.nsys - s0) : W; // real systems of this chunk
+    for (int g = 0; g < 4; g++) {
+        const int F = g < 2 ? 3 * n : g == 2 ? n : n * nba;
+        if (F == 0) continue;
+        double *aos = (g == 0 ? st.pos : g == 1 ? st.vel : g == 2 ? st.mass : st.battr) + s0 * F;
+        const bool zeros = TO_CHUNKS && g == 3 && !have_battr;
+        const int S = F | 1, total = W * F;
+        const int per_body = g < 2 ? 3 : g == 2 ? 1 : nba;            // fields of this group per body
+        const int row0 = g == 0 ? 0 : g == 1 ? 3 : g == 2 ? 6 : 7;    // first chunk row of the group
+        if (TO_CHUNKS) {
+            for (int i = t; i < total; i += 256) {
+                const int l = i / F, f = i - l * F;
+                tile[l * S + f] = (!zeros && l < r) ? aos[i] : 0.0;
+            }
+            __syncthreads();
+            for (int i = t; i < total; i += 256) {
+                const int f = i / W, l = i % W, b = f / per_body, q = f - b * per_body;
+                e.body[((k * n + b) * e.nbf + row0 + q) * W + l] = tile[l * S + f];
+            }
+        } else {
+            for (int i = t; i < total; i += 256) {
+                const int f = i / W, l = i % W, b = f / per_body, q = f - b * per_body;
+                tile[l * S + f] = e.body[((k * n + b) * e.nbf + row0 + q) * W + l];
+            }
+            __syncthreads();
+            for (int i = t; i < total; i += 256) {
+                const int l = i / F, f = i - l * F;
+                if (l < r) aos[i] = tile[l * S + f];
+            }
+        }
+        __syncthreads();
+    }
+    if (t >= W) return;
+    const size_t gid = s0 + t;
+    const bool real = t < r;
+    double *d = e.sysd + k * e.nsf * W + t;
+    int32_t *si = e.sysi + k * 2 * W + t;
+    if (TO_CHUNKS) {
+        d[0] = real ? st.time[gid] : 0.0;
+        for (int a = 0; a < nsa; a++) d[(size_t)(1 + a) * W] = (real && have_sattr) ? st.sattr[gid * nsa + a] : 0.0;
+        si[0] = real ? st.state[gid] : SWARM_HIP_DISABLED;
+        si[W] = real ? st.id[gid] : -1;
+    } else if (real) {
+        st.time[gid] = d[0];
+        for (int a = 0; a < nsa; a++) st.sattr[gid * nsa + a] = d[(size_t)(1 + a) * W];
+        st.state[gid] = si[0];
+        st.id[gid] = si[W];
+    }
+}
+
+// LDS-tiled kernel when its tile fits the default 64 KB of dynamic LDS, the lane-per-system one otherwise
+template <bool TO_CHUNKS>
+static void launch_aos_convert(const swarm_hip_ensemble_t *ens, const AosStage &st, bool have_battr, bool have_sattr) {
+    const size_t nchunk = (size_t)swarm_hip_nchunk(ens->nsys);
+    const size_t fmax = (size_t)ens->nbod * (ens->nbattr > 3 ? ens->nbattr : 3);
+    const size_t lds = (size_t)W * (fmax | 1) * sizeof(double);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL((aos_tile_kernel<TO_CHUNKS>), dim3((unsigned)nchunk), dim3(256), lds, 0, view_of(ens), st,
+                           have_battr, have_sattr);
+    else
+        hipLaunchKernelGGL((aos_convert_kernel<TO_CHUNKS>), dim3((unsigned)((nchunk * W + 255) / 256)), dim3(256), 0, 0,
+                           view_of(ens), st, have_battr, have_sattr);
+}
+
 static int grid_for(int nsys, int block) { return (int)(((long long)nsys + block - 1) / block); }
 
 } // namespace swh
@@ -662,9 +736,7 @@ int swarm_hip_upload_aos(const swarm_hip_ensemble_t *ens, const double *pos, con
     h2d(st.state, state, nsys * sizeof(int32_t));
     h2d(st.id, id, nsys * sizeof(int32_t));
     if (err == hipSuccess) {
-        const size_t nlanes = (size_t)swarm_hip_nchunk(ens->nsys) * W;
-        hipLaunchKernelGGL((aos_convert_kernel<true>), dim3((unsigned)((nlanes + 255) / 256)), dim3(256), 0, 0, view_of(ens),
-                           st, body_attr != nullptr, sys_attr != nullptr);
+        swh::launch_aos_convert<true>(ens, st, body_attr != nullptr, sys_attr != nullptr);
         err = hipGetLastError();
         if (err == hipSuccess) err = hipDeviceSynchronize();
     }
@@ -683,9 +755,7 @@ int swarm_hip_download_aos(const swarm_hip_ensemble_t *ens, double *pos, double 
     std::unique_lock<std::mutex> hold;
     rc = aos_stage_alloc(ens, st, hold);
     if (rc) return rc;
-    const size_t nlanes = (size_t)swarm_hip_nchunk(ens->nsys) * W;
-    hipLaunchKernelGGL((aos_convert_kernel<false>), dim3((unsigned)((nlanes + 255) / 256)), dim3(256), 0, 0, view_of(ens), st,
-                       true, true);
+    swh::launch_aos_convert<false>(ens, st, true, true);
     hipError_t err = hipGetLastError();
     auto d2h = [&](void *h, const void *d, size_t bytes) {
         if (err == hipSuccess && h && bytes) err = hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
