@@ -73,15 +73,18 @@ static EnsView view_of(const swarm_hip_ensemble_t *ens) {
 constexpr int MAX_DEV = 64;
 static int32_t *g_scratch[MAX_DEV] = {nullptr};
 
-static int scratch_for_current(int32_t **out) {
+static std::mutex g_scratch_mu[MAX_DEV]; // a device's counter has one user at a time
+
+// `hold` keeps the device's counter for the caller until it goes out of scope: swarm_hip_count_active runs
+// memset, kernel and copy on it, and two host threads (or streams) counting on one GPU must not interleave
+static int scratch_for_current(int32_t **out, std::unique_lock<std::mutex> &hold) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEV) {
         set_error("device ordinal %d out of range", dev);
         return SWARM_HIP_EINVAL;
     }
-    static std::mutex mu; // first use from two host threads on one device
-    std::lock_guard<std::mutex> lock(mu);
+    hold = std::unique_lock<std::mutex>(g_scratch_mu[dev]);
     if (!g_scratch[dev]) HIP_TRY(hipMalloc((void **)&g_scratch[dev], 256));
     *out = g_scratch[dev];
     return SWARM_HIP_OK;
@@ -456,7 +459,8 @@ const char *swarm_hip_version(void) { return "swarm_hip 0.1 (gfx950)"; }
 int swarm_hip_init(int device) {
     HIP_TRY(hipSetDevice(device));
     int32_t *s = nullptr;
-    return scratch_for_current(&s);
+    std::unique_lock<std::mutex> hold;
+    return scratch_for_current(&s, hold);
 }
 
 int64_t swarm_hip_nchunk(int32_t nsys) { return ((int64_t)nsys + W - 1) / W; }
@@ -614,7 +618,8 @@ int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_
     *count = 0;
     if (ens->nsys == 0) return SWARM_HIP_OK;
     int32_t *d = nullptr;
-    rc = scratch_for_current(&d);
+    std::unique_lock<std::mutex> hold; // released when the count has arrived on the host
+    rc = scratch_for_current(&d, hold);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(d, 0, sizeof(int32_t), st));
