@@ -159,6 +159,16 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
  * Synchronises `stream`; result in *count. */
 int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_t *count);
 
+/* The same count for callers that cannot allocate or synchronise (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Asynchronous on
+ * `stream`; the result goes to the caller's DEVICE int32 *d_count (written, not accumulated: it need not
+ * be cleared).  Calls no hipMalloc/hipFree: the per-workgroup partial counts live in a static device array
+ * of 64 KiB that every GPU the library runs on holds until the process ends (one int32 per 4096 systems),
+ * hence the limit nsys <= SWARM_HIP_NOALLOC_MAX_NSYS (larger: SWARM_HIP_EINVAL).  All calls on one GPU
+ * share that array: calls that overlap on one GPU (two streams, two host threads) race -- order them. */
+#define SWARM_HIP_NOALLOC_MAX_NSYS (1 << 26)
+int swarm_hip_count_active_noalloc(const swarm_hip_ensemble_t *ens, int32_t *d_count, void *stream);
+
 /* INACTIVE -> ACTIVE.  = reactivate_systems (swarm/gpu/utilities.cu:113-131) and
  * activate_inactive_systems (swarm/integrator.cpp:83-89). */
 int swarm_hip_reactivate(const swarm_hip_ensemble_t *ens, void *stream);

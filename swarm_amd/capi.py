@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswarm_hip.so")
 
 CHUNK = 64
+NOALLOC_MAX_NSYS = 1 << 26
 MIN_NBOD, MAX_NBOD = 3, 10
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP, IRK2, IRK2_CPU = range(1, 12)
@@ -48,6 +49,7 @@ SYMBOLS = [
     "swarm_hip_init", "swarm_hip_last_error", "swarm_hip_version", "swarm_hip_nchunk",
     "swarm_hip_body_bytes", "swarm_hip_sysd_bytes", "swarm_hip_sysi_bytes",
     "swarm_hip_snapshot_record_bytes", "swarm_hip_launch_integrator", "swarm_hip_count_active",
+    "swarm_hip_count_active_noalloc",
     "swarm_hip_reactivate", "swarm_hip_total_energy", "swarm_hip_energy_stats",
     "swarm_hip_import_ref_layout", "swarm_hip_export_ref_layout", "swarm_hip_upload_aos",
     "swarm_hip_download_aos", "swarm_hip_malloc", "swarm_hip_free", "swarm_hip_memset",
@@ -76,6 +78,7 @@ lib.swarm_hip_snapshot_record_bytes.argtypes = [C.c_int32]
 lib.swarm_hip_init.argtypes = [C.c_int]
 lib.swarm_hip_launch_integrator.argtypes = [C.POINTER(EnsembleStruct), C.POINTER(LaunchStruct)]
 lib.swarm_hip_count_active.argtypes = [C.POINTER(EnsembleStruct), C.c_void_p, C.POINTER(C.c_int32)]
+lib.swarm_hip_count_active_noalloc.argtypes = [C.POINTER(EnsembleStruct), C.c_void_p, C.c_void_p]
 lib.swarm_hip_reactivate.argtypes = [C.POINTER(EnsembleStruct), C.c_void_p]
 lib.swarm_hip_total_energy.argtypes = [C.POINTER(EnsembleStruct), C.c_void_p, C.c_void_p]
 lib.swarm_hip_energy_stats.argtypes = [C.POINTER(EnsembleStruct), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -90,6 +90,34 @@ static int scratch_for_current(int32_t **out, std::unique_lock<std::mutex> &hold
     return SWARM_HIP_OK;
 }
 
+// ---- the allocation-free active count (swarm_hip_count_active_noalloc) ------------------------
+// Its partial counts live in a file-scope device array instead of allocated memory: one int32 per
+// workgroup of the first pass.  Each GPU holds its own copy (64 KiB) from the load of the code object
+// to the end of the process.  `scratch` is a host-side stand-in here, not a device address: host
+// code uses the per-device pointer hipGetSymbolAddress returns (noalloc_scratch), never the name.
+constexpr int NOALLOC_SYS_PER_GROUP = 4096;                    // 256 threads x 16 systems
+constexpr int NOALLOC_GROUPS = SWARM_HIP_NOALLOC_MAX_NSYS / NOALLOC_SYS_PER_GROUP; // 16384
+static __device__ __align__(256) int32_t scratch[NOALLOC_GROUPS];
+static int32_t *g_noalloc_ptr[MAX_DEV] = {nullptr};
+static std::mutex g_noalloc_mu;
+
+static int noalloc_scratch(int32_t **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) {
+        set_error("device ordinal %d out of range", dev);
+        return SWARM_HIP_EINVAL;
+    }
+    std::lock_guard<std::mutex> lock(g_noalloc_mu);
+    if (!g_noalloc_ptr[dev]) {
+        int32_t *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return SWARM_HIP_OK;
+}
+
 // ---- utility kernels ---------------------------------------------------------------------
 // number_of_active_systems_kernel (swarm/gpu/utilities.cu:36-64) does one atomicAdd per ACTIVE
 // system; here one per wavefront (ballot + popcount).
@@ -99,6 +127,35 @@ __global__ void count_active_kernel(EnsView e, int32_t *out) {
     if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
     const unsigned long long m = __ballot(act);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// Two-pass count without atomics for swarm_hip_count_active_noalloc.  Pass 1: workgroup g counts the ACTIVE
+// systems among [g*4096, (g+1)*4096) -- a lane reads 16 state rows, consecutive lanes consecutive systems -- and
+// writes its sum to partial[g] (every slot the second pass reads is written: nothing has to start at zero).
+__global__ __launch_bounds__(256) void count_active_partial_kernel(EnsView e, int32_t *partial) {
+    __shared__ int wsum[4];
+    const long long base = (long long)blockIdx.x * NOALLOC_SYS_PER_GROUP;
+    int n = 0;
+#pragma unroll 4
+    for (int k = 0; k < NOALLOC_SYS_PER_GROUP / 256; k++) {
+        const long long gid = base + k * 256 + threadIdx.x;
+        bool act = false;
+        if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
+        n += __popcll(__ballot(act)); // wave-uniform
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// Pass 2: one workgroup adds the ngroups partial counts and stores the total.
+__global__ __launch_bounds__(256) void count_active_final_kernel(const int32_t *partial, int ngroups, int32_t *out) {
+    __shared__ int wsum[4];
+    int n = 0;
+    for (int g = threadIdx.x; g < ngroups; g += 256) n += partial[g];
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // reactivate_systems_kernel, swarm/gpu/utilities.cu:113-131
@@ -460,7 +517,9 @@ int swarm_hip_init(int device) {
     HIP_TRY(hipSetDevice(device));
     int32_t *s = nullptr;
     std::unique_lock<std::mutex> hold;
-    return scratch_for_current(&s, hold);
+    int rc = scratch_for_current(&s, hold);
+    if (rc) return rc;
+    return noalloc_scratch(&s); // resolve this device's copy of the static scratch array now
 }
 
 int64_t swarm_hip_nchunk(int32_t nsys) { return ((int64_t)nsys + W - 1) / W; }
@@ -629,6 +688,30 @@ int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_
     HIP_TRY(hipMemcpyAsync(count, d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return SWARM_HIP_OK;
+}
+
+int swarm_hip_count_active_noalloc(const swarm_hip_ensemble_t *ens, int32_t *d_count, void *stream) {
+    int rc = check_ens(ens);
+    if (rc) return rc;
+    if (!d_count) {
+        set_error("count_active_noalloc: d_count is NULL");
+        return SWARM_HIP_EINVAL;
+    }
+    if (ens->nsys > SWARM_HIP_NOALLOC_MAX_NSYS) {
+        set_error("count_active_noalloc: nsys=%d exceeds SWARM_HIP_NOALLOC_MAX_NSYS=%d (the static partial-count "
+                  "array has one slot per %d systems); use swarm_hip_count_active",
+                  ens->nsys, SWARM_HIP_NOALLOC_MAX_NSYS, NOALLOC_SYS_PER_GROUP);
+        return SWARM_HIP_EINVAL;
+    }
+    int32_t *partial = nullptr;
+    rc = noalloc_scratch(&partial);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int ngroups = (int)(((long long)ens->nsys + NOALLOC_SYS_PER_GROUP - 1) / NOALLOC_SYS_PER_GROUP);
+    if (ngroups > 0)
+        hipLaunchKernelGGL(count_active_partial_kernel, dim3(ngroups), dim3(256), 0, st, view_of(ens), partial);
+    hipLaunchKernelGGL(count_active_final_kernel, dim3(1), dim3(256), 0, st, partial, ngroups, d_count);
+    return check_launch("count_active_noalloc kernel launch");
 }
 
 int swarm_hip_reactivate(const swarm_hip_ensemble_t *ens, void *stream) {
