@@ -128,6 +128,12 @@ typedef struct swarm_hip_launch {
                                               ignored elsewhere).  No reference key. */
     double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
                                               monitor's dt is time_step=                 */
+    int32_t kepler_compensated;            /* kepler_compensated= (mvs; default 0; no reference key).  0: the f and g
+                                              functions of the Kepler drift exactly as propagators/keplerian.hpp:214-224
+                                              evaluates them, `dfdt = (f*dgdt - 1)/g` with f and dgdt rounded to doubles
+                                              next to 1 -- a deterministic error of ~1e-16/time_step per step.  1: the same
+                                              expressions evaluated from f-1 and dgdt-1 (no cancellation); DESIGN.md 4 */
+    int32_t reserved0;
     swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
     /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
     uint64_t *d_steps_accepted;

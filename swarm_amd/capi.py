@@ -39,6 +39,7 @@ class LaunchStruct(C.Structure):
                 ("log_on_close_encounter", C.c_int32), ("verbose_on_close_encounter", C.c_int32),
                 ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double), ("irk2_method", C.c_int32), ("log_transits", C.c_int32), ("log_occultations", C.c_int32),
                 ("lane_mode", C.c_int32), ("log_transit_tol", C.c_double),
+                ("kepler_compensated", C.c_int32), ("reserved0", C.c_int32),
                 ("log", LogStruct),
                 ("d_steps_accepted", C.c_void_p), ("d_steps_attempted", C.c_void_p),
                 ("stream", C.c_void_p)]

@@ -551,6 +551,7 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
     c.ip.error_tolerance = a->error_tolerance;
     c.ip.max_timestep = a->max_timestep;
     c.ip.timestep_scale = a->timestep_scale;
+    c.ip.kepler_compensated = a->kepler_compensated != 0;
     if (a->monitor < SWARM_HIP_MON_EJECTION || a->monitor > SWARM_HIP_MON_LOG_TRANSIT) {
         set_error("unknown monitor id %d", a->monitor);
         return SWARM_HIP_EINVAL;

@@ -57,6 +57,7 @@ struct IntParams {
     double destination_time;
     double time_step, time_step_factor, min_time_step, max_time_step, error_tolerance;
     double max_timestep, timestep_scale;
+    int kepler_compensated; // swarm_hip_launch_t::kepler_compensated (mvs)
 };
 
 // ---------------------------------------------------------------------------------------------

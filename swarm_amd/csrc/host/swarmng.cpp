@@ -346,6 +346,7 @@ public:
         if (MON == SWARM_HIP_MON_LOG_INTERVAL) a.log_interval = cfg.require("log_interval", 0.0); // log_time_interval.hpp:41
         if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_IRK2) a.rceh = cfg.optional("rceh", 1e-6); // mce_stat_params, mercury_mce_stat.hpp:47
         if (ID == SWARM_HIP_IRK2) a.irk2_method = cfg.optional("method", 6); // irk2_integrator.hpp:53
+        if (ID == SWARM_HIP_MVS) a.kepler_compensated = cfg.optional("kepler_compensated", 0); // not a reference key
         a.lane_mode = cfg.optional("lane_mode", 0); // not a reference key: 0 auto, 1 lane per system, 2 lane per body
     }
     // = launch_templatized_integrator(this), swarm/gpu/helpers.hpp:216-238: ONE C-ABI call

@@ -54,67 +54,8 @@ __device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
     }
 }
 
-// solvex, keplerian.hpp:120-159: Laguerre n=5, <= 7 iterations, early exit `i>2 && x+u==x`
-__device__ __forceinline__ double solvex(double r0dotv0, double alpha, double sqrtM1, double r0, double dt) {
-    const double N_LAG = 5.0;
-    const double smu = sqrtM1;
-    const double foo = 1.0 - r0 * alpha;
-    const double sig0 = fdiv(r0dotv0, smu);
-    double x = fdiv(sqrtM1 * sqrtM1 * dt * dt, r0);
-    double u = 1.0;
-    for (int i = 0; (i < 7) && !((i > 2) && (x + u == x)); i++) {
-        const double x2 = x * x, x3 = x2 * x, alx2 = alpha * x2;
-        double Cp, Sp;
-        SC_prussing(alx2, Sp, Cp);
-        const double F = sig0 * x2 * Cp + foo * x3 * Sp + r0 * x - smu * dt;
-        const double dF = sig0 * x * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
-        const double ddF = sig0 * (1.0 - alx2 * Cp) + foo * x * (1.0 - alx2 * Sp);
-        double z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
-        z = fsqrt(z);
-        double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
-        if (denom == 0.0) denom = 1e-8;
-        u = fdiv(N_LAG * F, denom);
-        x -= u;
-    }
-    return x;
-}
-
-// drift_kepler, keplerian.hpp:175-236
-__device__ __forceinline__ void drift_kepler(double (&p)[3], double (&v)[3], const double sqrtGM,
-                                             const double deltaTime) {
-    const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
-    const double r0 = fsqrt(x_old * x_old + y_old * y_old + z_old * z_old);
-    const double v2 = (vx_old * vx_old + vy_old * vy_old + vz_old * vz_old);
-    const double r0dotv0 = (x_old * vx_old + y_old * vy_old + z_old * vz_old);
-    const double GM = sqrtGM * sqrtGM;
-    const double alpha = (fdiv(2.0, r0) - fdiv(v2, GM));
-    const double x_p = solvex(r0dotv0, alpha, sqrtGM, r0, deltaTime);
-    const double smu = sqrtGM;
-    const double foo = 1.0 - r0 * alpha;
-    const double sig0 = fdiv(r0dotv0, smu);
-    const double x2 = x_p * x_p, x3 = x2 * x_p, alx2 = alpha * x2;
-    double Cp, Sp;
-    SC_prussing(alx2, Sp, Cp);
-    double r = sig0 * x_p * (1.0 - alx2 * Sp) + foo * x2 * Cp + r0;
-    if (r < 0.) r = 0.;
-    const double f_p = 1.0 - fdiv(x2, r0) * Cp;
-    const double g_p = deltaTime - fdiv(x3, smu) * Sp;
-    double dfdt;
-    const double dgdt = 1.0 - fdiv(x2, r) * Cp;
-    if (fabs(g_p) > 1e-8)
-        dfdt = fdiv(f_p * dgdt - 1.0, g_p);
-    else
-        dfdt = fdiv(x_p * smu, r * r0) * (alx2 * Sp - 1.0);
-    p[0] = f_p * x_old + g_p * vx_old;
-    p[1] = f_p * y_old + g_p * vy_old;
-    p[2] = f_p * z_old + g_p * vz_old;
-    v[0] = dfdt * x_old + dgdt * vx_old;
-    v[1] = dfdt * y_old + dgdt * vy_old;
-    v[2] = dfdt * z_old + dgdt * vz_old;
-}
-
-// Kepler drift of G planets in lockstep: the same arithmetic per planet as drift_kepler/solvex
-// above (keplerian.hpp:120-236), but the Laguerre iterations of the G planets advance together so
+// Kepler drift of G planets in lockstep: the arithmetic per planet of solvex and drift_kepler
+// (keplerian.hpp:120-159, 175-236), but the Laguerre iterations of the G planets advance together so
 // that their G independent dependency chains interleave (one lane owns the whole system, so
 // without this every iteration is one long serial chain of FP64 latencies).  A planet whose own
 // loop condition `(i < 7) && !((i > 2) && (x + u == x))` has failed keeps its x (select, no
@@ -140,7 +81,8 @@ __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], d
 }
 
 template <int N, int B0, int G>
-__device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqrtGM, const double deltaTime) {
+__device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqrtGM, const double deltaTime,
+                                                   const bool compensated) {
     const double N_LAG = 5.0;
     const double smu = sqrtGM;
     const double GM = sqrtGM * sqrtGM;
@@ -203,20 +145,41 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
         const double x_p = x[g], x2 = x_p * x_p, x3 = x2 * x_p;
         double r = sig0[g] * x_p * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
         if (r < 0.) r = 0.;
-        const double f_p = 1.0 - (x2 * inv_r0[g]) * Cp[g];
         const double g_p = deltaTime - (x3 * inv_smu) * Sp[g];
-        const double dgdt = 1.0 - fdiv(x2, r) * Cp[g];
-        double dfdt;
-        if (fabs(g_p) > 1e-8)
-            dfdt = fdiv(f_p * dgdt - 1.0, g_p);
-        else
-            dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
-        p[0] = f_p * x_old + g_p * vx_old;
-        p[1] = f_p * y_old + g_p * vy_old;
-        p[2] = f_p * z_old + g_p * vz_old;
-        v[0] = dfdt * x_old + dgdt * vx_old;
-        v[1] = dfdt * y_old + dgdt * vy_old;
-        v[2] = dfdt * z_old + dgdt * vz_old;
+        if (!compensated) { // keplerian.hpp:214-231 as written
+            const double f_p = 1.0 - (x2 * inv_r0[g]) * Cp[g];
+            const double dgdt = 1.0 - fdiv(x2, r) * Cp[g];
+            double dfdt;
+            if (fabs(g_p) > 1e-8)
+                dfdt = fdiv(f_p * dgdt - 1.0, g_p);
+            else
+                dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
+            p[0] = f_p * x_old + g_p * vx_old;
+            p[1] = f_p * y_old + g_p * vy_old;
+            p[2] = f_p * z_old + g_p * vz_old;
+            v[0] = dfdt * x_old + dgdt * vx_old;
+            v[1] = dfdt * y_old + dgdt * vy_old;
+            v[2] = dfdt * z_old + dgdt * vz_old;
+        } else {
+            // The same expressions in terms of fh = f - 1 and gh = dg/dt - 1: f*dgdt - 1 = fh + gh + fh*gh.  Written
+            // with f and dgdt, both within ~GM dt^2/r^3 of 1, the difference f*dgdt - 1 keeps only the digits of fh
+            // and gh above the spacing of the doubles at 1 (1.1e-16), an error of ~1e-16/dt in dfdt that repeats with
+            // the same sign step after step (MVS.cfg, dt = 3e-4: 6e-9 ... 9e-8 in velocity at T = 1 for nbod 3..8,
+            // tools/mvs_parity.py).  swarm_hip_launch_t::kepler_compensated, not a reference key.
+            const double fh = -((x2 * inv_r0[g]) * Cp[g]);
+            const double gh = -(fdiv(x2, r) * Cp[g]);
+            double dfdt;
+            if (fabs(g_p) > 1e-8)
+                dfdt = fdiv(fh + gh + fh * gh, g_p);
+            else
+                dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
+            p[0] = x_old + (fh * x_old + g_p * vx_old);
+            p[1] = y_old + (fh * y_old + g_p * vy_old);
+            p[2] = z_old + (fh * z_old + g_p * vz_old);
+            v[0] = vx_old + (dfdt * x_old + gh * vx_old);
+            v[1] = vy_old + (dfdt * y_old + gh * vy_old);
+            v[2] = vz_old + (dfdt * z_old + gh * vz_old);
+        }
     }
 }
 
@@ -226,11 +189,12 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
 #endif
 constexpr int KEPLER_GROUP = SWH_KEPLER_GROUP;
 template <int N, int B0 = 1>
-__device__ __forceinline__ void drift_kepler_all(State<N> &s, const double sqrtGM, const double deltaTime) {
+__device__ __forceinline__ void drift_kepler_all(State<N> &s, const double sqrtGM, const double deltaTime,
+                                                 const bool compensated) {
     if constexpr (B0 < N) {
         constexpr int G = (N - B0 < KEPLER_GROUP) ? (N - B0) : KEPLER_GROUP;
-        drift_kepler_group<N, B0, G>(s, sqrtGM, deltaTime);
-        drift_kepler_all<N, B0 + G>(s, sqrtGM, deltaTime);
+        drift_kepler_group<N, B0, G>(s, sqrtGM, deltaTime, compensated);
+        drift_kepler_all<N, B0 + G>(s, sqrtGM, deltaTime, compensated);
     }
 }
 
@@ -391,7 +355,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
-                drift_kepler_all<N>(s, sqrtGM, 2.0 * hby2);
+                drift_kepler_all<N>(s, sqrtGM, 2.0 * hby2, ip.kepler_compensated != 0);
                 acc_only<N, true>(s.p, s.m, acc);
 #pragma unroll
                 for (int b = 1; b < N; b++)

@@ -263,6 +263,8 @@ class GpuIntegrator(Integrator):
             a.rceh = cfg.optional("rceh", 1e-6)
         if self.int_id == capi.IRK2:                                  # irk2_integrator.hpp:53
             a.irk2_method = cfg.optional("method", 6)
+        if self.int_id == capi.MVS:                                   # not a reference key, see include/swarm_hip.h
+            a.kepler_compensated = int(cfg.optional("kepler_compensated", 0))
         a.lane_mode = cfg.optional("lane_mode", 0)                     # not a reference key: 0 auto, 1 per system, 2 per body
         self.args = a
         self.steps_accepted = None
