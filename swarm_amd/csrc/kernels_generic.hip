@@ -54,55 +54,94 @@ __device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
     }
 }
 
-// Kepler drift of G planets in lockstep: the arithmetic per planet of solvex and drift_kepler
-// (keplerian.hpp:120-159, 175-236), but the Laguerre iterations of the G planets advance together so
-// that their G independent dependency chains interleave (one lane owns the whole system, so
-// without this every iteration is one long serial chain of FP64 latencies).  A planet whose own
-// loop condition `(i < 7) && !((i > 2) && (x + u == x))` has failed keeps its x (select, no
-// branch).  The Stumpff functions take the series branch of SC_prussing for all planets with one
-// wave-uniform test when every lane is in that regime (|alpha x^2| < 1e-4, the usual case for
-// dt << orbital period), and the general per-planet routine otherwise.
-__device__ __forceinline__ void SC_series(double y, double &S, double &C) { // keplerian.hpp:63-66
-    S = (1.0 / 6.0) * (1.0 - y * (1.0 / 20.0) * (1.0 - y * (1.0 / 42.0) * (1.0 - y * (1.0 / 72.0))));
-    C = (1.0 / 2.0) * (1.0 - y * (1.0 / 12.0) * (1.0 - y * (1.0 / 30.0) * (1.0 - y * (1.0 / 56.0))));
+// Kepler drift of G planets in lockstep: per planet the iteration of solvex and the f, g update of drift_kepler
+// (keplerian.hpp:120-159, 175-236), with the Laguerre iterations of the G planets advancing together so that their G
+// independent dependency chains interleave (one lane owns the whole system, so without this every iteration is one
+// long serial chain of FP64 latencies).  A planet whose own loop condition `(i < 7) && !((i > 2) && (x + u == x))` has
+// failed keeps its x (select, no branch).  The Stumpff functions take the series branch of SC_prussing for all planets
+// with one wave-uniform test when every lane is in that regime (|alpha x^2| < 1e-4, the usual case for dt << orbital
+// period), and the general per-planet routine otherwise.
+//
+// The expressions are the reference's, regrouped so that one pass is ~45 issue slots instead of ~70 (the solver is
+// three quarters of an MVS step):
+//   S, C series       Horner in y with the expanded coefficients 1/3!, -1/5!, 1/7!, -1/9! and 1/2!, -1/4!, 1/6!, -1/8!
+//                     (keplerian.hpp:65-66 nests the same polynomial as products of (1 - y/k (...)))
+//   F                 x (sig0 xC + foo x^2 S + r0) - smu dt            (L146: sig0 x^2 C + foo x^3 S + r0 x - smu dt)
+//   dF                (sig0 x)(1 - yS) + foo x (xC) + r0               (L147)
+//   ddF               sig0 (1 - yC) + foo (x (1 - yS))                 (L148)
+//   z                 |16 dF^2 - 20 F ddF|                             (L149 with n = 5 written out)
+//   r0, 1/r0          one rsqrt of |p|^2 gives both
+// each value within an ulp or two of the reference's association; what the tests hold is 1e-10 against the CPU
+// restatement (and 4e-12 at MVS.cfg's step, tests/test_gpu_integrators.py).
+__device__ __forceinline__ void SC_series(const double y, double &S, double &C) {
+    S = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, -1.0 / 362880.0, 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+    C = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
+}
+// The general routine, out of line and marked cold.  Inlined (14 copies of sincos/sinh/cosh at nbod 8) its register
+// needs put ~55 spill stores and reloads per step on the hot path of a kernel that never takes it -- 7.2 GB of scratch
+// traffic per C4-shard launch; measured on that shard (series regime): inline 14.3 ms, inline behind a branch-weight
+// hint 12.2 ms, this 10.8 ms, no general path at all 10.3 ms; in the trigonometric regime (systems shrunk 30x) 37.7 ms
+// inline against 19.1 ms.
+static __device__ __attribute__((noinline, cold)) void SC_prussing_outlined(double y, double *sc) {
+    double S, C;
+    SC_prussing(y, S, C);
+    sc[0] = S, sc[1] = C;
 }
 template <int G>
 __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], double (&C)[G]) {
     bool small = true;
 #pragma unroll
     for (int g = 0; g < G; g++) small = small && (fabs(y[g]) < 1e-4);
-    if (__all(small)) {
+    if (__builtin_expect(__all(small), 1)) {
 #pragma unroll
         for (int g = 0; g < G; g++) SC_series(y[g], S[g], C[g]);
     } else {
+#ifndef SWH_EXPERIMENT_SERIES_ONLY /* ceiling experiment: no general Stumpff path at all; never in the shipped build */
 #pragma unroll
-        for (int g = 0; g < G; g++) SC_prussing(y[g], S[g], C[g]);
+        for (int g = 0; g < G; g++) {
+            double sc[2];
+            SC_prussing_outlined(y[g], sc);
+            S[g] = sc[0], C[g] = sc[1];
+        }
+#endif
     }
 }
 
+// what the solver needs of the star and of the step; formed when the step size changes (once per launch, and again
+// for a clipped last step)
+struct KeplerConsts {
+    double smu, inv_smu, inv_GM; // sqrt(GM) of the star, its reciprocal, 1/GM
+    double dt, smudt, gmdt2;     // the drift's time span, smu dt, GM dt^2 (the numerator of solvex's initial guess)
+    __device__ __forceinline__ void set_star(const double sqrtGM) {
+        smu = sqrtGM;
+        inv_smu = rcp_full(sqrtGM);
+        inv_GM = rcp_full(sqrtGM * sqrtGM);
+        dt = -1.0;
+    }
+    __device__ __forceinline__ void set_dt(const double deltaTime) {
+        dt = deltaTime;
+        smudt = smu * deltaTime;
+        gmdt2 = smu * smu * deltaTime * deltaTime;
+    }
+};
+
 template <int N, int B0, int G>
-__device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqrtGM, const double deltaTime,
-                                                   const bool compensated) {
-    const double N_LAG = 5.0;
-    const double smu = sqrtGM;
-    const double GM = sqrtGM * sqrtGM;
-    // a / b is a * rcp_full(b) throughout (fdiv): the reciprocals of the launch constants and of r0 are
-    // formed once and shared, which leaves the products unchanged
-    const double inv_smu = rcp_full(smu), inv_GM = rcp_full(GM);
+__device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerConsts &k, const bool compensated) {
     double r0[G], inv_r0[G], alpha[G], sig0[G], foo[G], x[G], u[G];
     bool live[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const double(&p)[3] = s.p[B0 + g];
         const double(&v)[3] = s.v[B0 + g];
-        r0[g] = fsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-        inv_r0[g] = rcp_full(r0[g]);
+        const double rr = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        inv_r0[g] = rsqrt_full(rr);
+        r0[g] = rr * inv_r0[g];
         const double v2 = (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         const double r0dotv0 = (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]);
-        alpha[g] = (2.0 * inv_r0[g] - v2 * inv_GM);
+        alpha[g] = (2.0 * inv_r0[g] - v2 * k.inv_GM);
         foo[g] = 1.0 - r0[g] * alpha[g];
-        sig0[g] = r0dotv0 * inv_smu;
-        x[g] = (sqrtGM * sqrtGM * deltaTime * deltaTime) * inv_r0[g];
+        sig0[g] = r0dotv0 * k.inv_smu;
+        x[g] = k.gmdt2 * inv_r0[g];
         u[g] = 1.0;
         live[g] = true;
     }
@@ -113,47 +152,65 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
             live[g] = live[g] && !((i > 2) && (x[g] + u[g] == x[g]));
             any = any || live[g];
         }
-        if (!any) break;
-        double alx2[G], Sp[G], Cp[G];
+        if (!__any(any)) break;
+        double y[G], Sp[G], Cp[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) alx2[g] = alpha[g] * (x[g] * x[g]);
-        SC_group<G>(alx2, Sp, Cp);
+        for (int g = 0; g < G; g++) y[g] = alpha[g] * (x[g] * x[g]);
+        SC_group<G>(y, Sp, Cp);
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const double x2 = x[g] * x[g], x3 = x2 * x[g];
-            const double F = sig0[g] * x2 * Cp[g] + foo[g] * x3 * Sp[g] + r0[g] * x[g] - smu * deltaTime;
-            const double dF = sig0[g] * x[g] * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
-            const double ddF = sig0[g] * (1.0 - alx2[g] * Cp[g]) + foo[g] * x[g] * (1.0 - alx2[g] * Sp[g]);
-            double z = fabs((N_LAG - 1.0) * ((N_LAG - 1.0) * dF * dF - N_LAG * F * ddF));
-            z = fsqrt(z);
-            double denom = (dF + ((dF) < 0 ? -1 : 1) * z);
+            const double xx = x[g], x2 = xx * xx;
+            const double a = __builtin_fma(-y[g], Sp[g], 1.0), b = __builtin_fma(-y[g], Cp[g], 1.0);
+            const double xC = xx * Cp[g], x2S = x2 * Sp[g];
+            const double F = __builtin_fma(xx, __builtin_fma(sig0[g], xC, __builtin_fma(foo[g], x2S, r0[g])), -k.smudt);
+            const double dF = __builtin_fma(sig0[g] * xx, a, __builtin_fma(foo[g], xx * xC, r0[g]));
+            const double ddF = __builtin_fma(sig0[g], b, foo[g] * (xx * a));
+            const double az = fabs(__builtin_fma(16.0 * dF, dF, -20.0 * (F * ddF)));
+            const double z = az * rsqrt_full(fmax(az, 1e-300)); // sqrt; 0 for az = 0
+            double denom = dF < 0 ? dF - z : dF + z;
             if (denom == 0.0) denom = 1e-8;
-            const double un = fdiv(N_LAG * F, denom);
+            const double un = (5.0 * F) * rcp_full(denom);
             u[g] = live[g] ? un : u[g];
-            x[g] = live[g] ? x[g] - un : x[g];
+            x[g] = live[g] ? xx - un : xx;
         }
     }
-    double alx2[G], Sp[G], Cp[G];
+    double y[G], Sp[G], Cp[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) alx2[g] = alpha[g] * (x[g] * x[g]);
-    SC_group<G>(alx2, Sp, Cp);
+    for (int g = 0; g < G; g++) y[g] = alpha[g] * (x[g] * x[g]);
+    SC_group<G>(y, Sp, Cp);
 #pragma unroll
     for (int g = 0; g < G; g++) {
         double(&p)[3] = s.p[B0 + g];
         double(&v)[3] = s.v[B0 + g];
         const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
-        const double x_p = x[g], x2 = x_p * x_p, x3 = x2 * x_p;
-        double r = sig0[g] * x_p * (1.0 - alx2[g] * Sp[g]) + foo[g] * x2 * Cp[g] + r0[g];
+        const double x_p = x[g], x2 = x_p * x_p;
+        const double a = __builtin_fma(-y[g], Sp[g], 1.0);
+        const double x2C = x2 * Cp[g];
+        double r = __builtin_fma(sig0[g] * x_p, a, __builtin_fma(foo[g], x2C, r0[g]));
         if (r < 0.) r = 0.;
-        const double g_p = deltaTime - (x3 * inv_smu) * Sp[g];
-        if (!compensated) { // keplerian.hpp:214-231 as written
-            const double f_p = 1.0 - (x2 * inv_r0[g]) * Cp[g];
-            const double dgdt = 1.0 - fdiv(x2, r) * Cp[g];
-            double dfdt;
-            if (fabs(g_p) > 1e-8)
-                dfdt = fdiv(f_p * dgdt - 1.0, g_p);
-            else
-                dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
+        const double g_p = __builtin_fma(-(x2 * x_p) * k.inv_smu, Sp[g], k.dt);
+        // fh = f - 1 and gh = dg/dt - 1 (keplerian.hpp:214, 218)
+        const double fh = -(x2C * inv_r0[g]);
+        const double gh = -(x2C * rcp_full(r));
+        double f_p, dgdt, num;
+        if (!compensated) { // keplerian.hpp:214-231 as written: f and dg/dt rounded to doubles next to 1
+            f_p = 1.0 + fh;
+            dgdt = 1.0 + gh;
+            num = __builtin_fma(f_p, dgdt, -1.0);
+        } else {
+            // The same expressions in terms of fh and gh: f*dgdt - 1 = fh + gh + fh*gh.  Written with f and dgdt, both
+            // within ~GM dt^2/r^3 of 1, the difference f*dgdt - 1 keeps only the digits of fh and gh above the spacing
+            // of the doubles at 1 (1.1e-16), an error of ~1e-16/dt in dfdt that repeats with the same sign step after
+            // step (MVS.cfg, dt = 3e-4: 6e-9 ... 9e-8 in velocity at T = 1 for nbod 3..8, tools/mvs_parity.py).
+            // swarm_hip_launch_t::kepler_compensated, not a reference key.
+            num = fh + gh + fh * gh;
+        }
+        double dfdt = num * rcp_full(g_p);
+        if (__builtin_expect(__any(!(fabs(g_p) > 1e-8)), 0)) { // L222-224, a step too short for the quotient
+            const double alt = fdiv(x_p * k.smu, r * r0[g]) * (y[g] * Sp[g] - 1.0);
+            dfdt = fabs(g_p) > 1e-8 ? dfdt : alt;
+        }
+        if (!compensated) {
             p[0] = f_p * x_old + g_p * vx_old;
             p[1] = f_p * y_old + g_p * vy_old;
             p[2] = f_p * z_old + g_p * vz_old;
@@ -161,18 +218,6 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
             v[1] = dfdt * y_old + dgdt * vy_old;
             v[2] = dfdt * z_old + dgdt * vz_old;
         } else {
-            // The same expressions in terms of fh = f - 1 and gh = dg/dt - 1: f*dgdt - 1 = fh + gh + fh*gh.  Written
-            // with f and dgdt, both within ~GM dt^2/r^3 of 1, the difference f*dgdt - 1 keeps only the digits of fh
-            // and gh above the spacing of the doubles at 1 (1.1e-16), an error of ~1e-16/dt in dfdt that repeats with
-            // the same sign step after step (MVS.cfg, dt = 3e-4: 6e-9 ... 9e-8 in velocity at T = 1 for nbod 3..8,
-            // tools/mvs_parity.py).  swarm_hip_launch_t::kepler_compensated, not a reference key.
-            const double fh = -((x2 * inv_r0[g]) * Cp[g]);
-            const double gh = -(fdiv(x2, r) * Cp[g]);
-            double dfdt;
-            if (fabs(g_p) > 1e-8)
-                dfdt = fdiv(fh + gh + fh * gh, g_p);
-            else
-                dfdt = fdiv(x_p * smu, r * r0[g]) * (alx2[g] * Sp[g] - 1.0);
             p[0] = x_old + (fh * x_old + g_p * vx_old);
             p[1] = y_old + (fh * y_old + g_p * vy_old);
             p[2] = z_old + (fh * z_old + g_p * vz_old);
@@ -189,12 +234,11 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const double sqr
 #endif
 constexpr int KEPLER_GROUP = SWH_KEPLER_GROUP;
 template <int N, int B0 = 1>
-__device__ __forceinline__ void drift_kepler_all(State<N> &s, const double sqrtGM, const double deltaTime,
-                                                 const bool compensated) {
+__device__ __forceinline__ void drift_kepler_all(State<N> &s, const KeplerConsts &k, const bool compensated) {
     if constexpr (B0 < N) {
         constexpr int G = (N - B0 < KEPLER_GROUP) ? (N - B0) : KEPLER_GROUP;
-        drift_kepler_group<N, B0, G>(s, sqrtGM, deltaTime, compensated);
-        drift_kepler_all<N, B0 + G>(s, sqrtGM, deltaTime, compensated);
+        drift_kepler_group<N, B0, G>(s, k, compensated);
+        drift_kepler_all<N, B0 + G>(s, k, compensated);
     }
 }
 
@@ -324,11 +368,12 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
         MonState ms;
         mon_init(ms, s);
         double acc[N][3];
-        double sqrtGM = 0., timestep = 0.;
+        double timestep = 0.;
         const double inv_m0 = 1.0 / s.m[0];
+        KeplerConsts kc;
         // prop.init()
         if (KIND == SWARM_HIP_MVS) {
-            sqrtGM = sqrt(s.m[0]);
+            kc.set_star(sqrt(s.m[0]));
             mvs_to_internal(s);
             acc_only<N, true>(s.p, s.m, acc);
         } else if (KIND == SWARM_HIP_VERLET) {
@@ -355,7 +400,8 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
-                drift_kepler_all<N>(s, sqrtGM, 2.0 * hby2, ip.kepler_compensated != 0);
+                if (2.0 * hby2 != kc.dt) kc.set_dt(2.0 * hby2);
+                drift_kepler_all<N>(s, kc, ip.kepler_compensated != 0);
                 acc_only<N, true>(s.p, s.m, acc);
 #pragma unroll
                 for (int b = 1; b < N; b++)
