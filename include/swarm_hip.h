@@ -84,7 +84,9 @@ typedef struct swarm_hip_ensemble {
  * d_cursor[0] = bytes used, d_cursor[2] = lprintf (MSG_PRINTF) records among them (so that a flush
  * only walks the buffer for replay_printf when there is something to print), d_cursor[3] reserved,
  * d_cursor[1] = records dropped because the buffer was full
- * (the reference drops them silently, bits/gpulog_write.h:14-22). */
+ * (the reference drops them silently, bits/gpulog_write.h:14-22).
+ * Read or clear the buffer and its cursor only after the launch stream has been synchronised: a flush that
+ * overlaps a running kernel loses the records appended after the copy. */
 typedef struct swarm_hip_log {
     uint8_t *d_buf;
     int32_t *d_cursor; /* int32[4], zeroed by the caller */

@@ -220,17 +220,13 @@ void integrator::integrate() {
         if (number_of_active_systems(_ens) == 0) break;
     }
 }
+// integrator.cpp:129-145: the plugin "integrator_<name>" builds the object; an unknown name is a configuration error
 Pintegrator integrator::create(const config &cfg) {
-    Pintegrator integ;
-    if (!cfg.count("integrator")) ERROR("Integrator type has to be chosen with 'integrator=xxx' keyword");
-    std::string name = cfg.at("integrator");
-    std::string plugin_name = "integrator_" + name;
-    try {
-        integ.reset((integrator *)plugin::instance(plugin_name, cfg));
-    } catch (plugin_not_found &e) {
-        ERROR("Integrator " + name + " not found.");
-    }
-    return integ;
+    const config::const_iterator chosen = cfg.find("integrator");
+    if (chosen == cfg.end()) ERROR("Integrator type has to be chosen with 'integrator=xxx' keyword");
+    plugins_map_t::const_iterator entry = plugins_map().find("integrator_" + chosen->second);
+    if (entry == plugins_map().end() || !entry->second) ERROR("Integrator " + chosen->second + " not found.");
+    return Pintegrator(static_cast<integrator *>(entry->second->create(cfg)));
 }
 
 // ---- gpu::integrator -------------------------------------------------------------------------
@@ -403,121 +399,192 @@ void init(const config &cfg) {
     log::manager::default_log()->init(cfg);
 }
 
-// ---- snapshot: swarm/snapshot.cpp ------------------------------------------------------------
+// ---- snapshot: the two ensemble file formats of swarm/snapshot.{hpp,cpp} --------------------------------------------
+// One description of what a file holds, read and written by two codecs.  A file is a header (nbod, nsys and the
+// attribute counts), then per system a system record and nbod body records.  The formats differ in the order of the
+// fields inside a record and in how a number is encoded:
+//   binary (snapshot.hpp:153-170)  header {nsys, nbod, nsysattr, nbodattr} as int32; sys {time, id, state, attr[]};
+//                                  body {pos[3], vel[3], mass, attr[]}; doubles and int32 as they are in memory
+//   text   (snapshot.cpp:181-216)  "SwarmDataFile 2" / "nbod nsys nsysattr nbodattr" / "id time state" / attributes /
+//                                  per body mass, position, velocity, attributes; every real as %.15le
+// A file may carry fewer attributes than the library has (the rest stay 0), never more.
 namespace snapshot {
+namespace {
 
-template <class T> static void readfromFILE(FILE *f, T &t, const std::string &fn) {
-    if (fread(&t, 1, sizeof(t), f) != sizeof(t)) throw readfileexception(fn, "File I/O error");
-}
-template <class T> static void writetoFILE(FILE *f, const T &t, const std::string &fn) {
-    if (fwrite(&t, 1, sizeof(t), f) != sizeof(t)) throw writefileexception(fn, "File I/O error");
+enum Field { F_ID, F_TIME, F_STATE, F_SYS_ATTR, F_MASS, F_POS, F_VEL, F_BODY_ATTR };
+// one field of a record; `after` is what the text writer puts behind (each element of) it
+struct Slot {
+    Field field;
+    const char *after;
+};
+const Slot BINARY_SYS[] = {{F_TIME, ""}, {F_ID, ""}, {F_STATE, ""}, {F_SYS_ATTR, ""}};
+const Slot BINARY_BODY[] = {{F_POS, ""}, {F_VEL, ""}, {F_MASS, ""}, {F_BODY_ATTR, ""}};
+const Slot TEXT_SYS[] = {{F_ID, " "}, {F_TIME, " "}, {F_STATE, "\n"}, {F_SYS_ATTR, " "}};
+const Slot TEXT_BODY[] = {{F_MASS, "\n\t"}, {F_POS, " "}, {F_VEL, " "}, {F_BODY_ATTR, " "}};
+const char *TEXT_TAG = "SwarmDataFile";
+const int TEXT_VERSION = 2;
+
+struct Counts {
+    int nsys, nbod, nsysattr, nbodattr;
+};
+
+// where the elements of a field live in the host ensemble
+struct Span {
+    double *real;
+    int *integer;
+    int count;
+};
+Span locate(ensemble::Data &d, Field f, int sys, int bod, const Counts &c) {
+    const size_t sb = (size_t)sys * d.nbod + bod;
+    switch (f) {
+    case F_ID: return Span{0, &d.id[sys], 1};
+    case F_STATE: return Span{0, &d.state[sys], 1};
+    case F_TIME: return Span{&d.time[sys], 0, 1};
+    case F_SYS_ATTR: return Span{d.sattr.data() + (size_t)sys * ensemble::NUM_SYS_ATTRIBUTES, 0, c.nsysattr};
+    case F_MASS: return Span{&d.mass[sb], 0, 1};
+    case F_POS: return Span{&d.pos[sb * 3], 0, 3};
+    case F_VEL: return Span{&d.vel[sb * 3], 0, 3};
+    case F_BODY_ATTR: return Span{d.battr.data() + sb * ensemble::NUM_BODY_ATTRIBUTES, 0, c.nbodattr};
+    }
+    return Span{0, 0, 0};
 }
 
-defaultEnsemble load(const std::string &filename) {
-    FILE *f = fopen(filename.c_str(), "rb");
-    if (!f) throw readfileexception(filename, "cannot open file");
-    header h; sys s; body b;
-    readfromFILE(f, h, filename);
-    if (h.nsysattr > ensemble::NUM_SYS_ATTRIBUTES)
-        throw readfileexception(filename, "The file requires more system attributes than the library can handle");
-    if (h.nbodattr > ensemble::NUM_BODY_ATTRIBUTES)
-        throw readfileexception(filename, "The file requires more planet attributes than the library can handle");
-    hostEnsemble ens = hostEnsemble::create(h.nbod, h.nsys);
-    for (int i = 0; i < h.nsys; i++) {
-        ensemble::SystemRef sr = ens[i];
-        readfromFILE(f, s, filename);
-        sr.id() = s.id, sr.time() = s.time, sr.state() = s.state;
-        for (int l = 0; l < h.nsysattr; l++) sr.attribute(l) = s.attribute[l];
-        for (int j = 0; j < h.nbod; j++) {
-            readfromFILE(f, b, filename);
-            sr[j].mass() = b.mass;
-            for (int c = 0; c < 3; c++) sr[j][c].pos() = b.pos[c], sr[j][c].vel() = b.vel[c];
-            for (int l = 0; l < h.nbodattr; l++) sr[j].attribute(l) = b.attribute[l];
+// ---- codecs: how one number, and the punctuation around records, goes to or comes from the file
+struct BinaryIn {
+    FILE *f;
+    const std::string &fn;
+    template <class T> void number(T &v, const char *) {
+        if (fread(&v, 1, sizeof(T), f) != sizeof(T)) throw readfileexception(fn, "File I/O error");
+    }
+    void text(const char *) {}
+};
+struct BinaryOut {
+    FILE *f;
+    const std::string &fn;
+    template <class T> void number(T &v, const char *) {
+        if (fwrite(&v, 1, sizeof(T), f) != sizeof(T)) throw writefileexception(fn, "File I/O error");
+    }
+    void text(const char *) {}
+};
+struct TextIn { // numbers separated by any white space, as fscanf takes them
+    FILE *f;
+    const std::string &fn;
+    void number(double &v, const char *) {
+        if (fscanf(f, "%le", &v) != 1) throw readfileexception(fn, "File I/O error");
+    }
+    void number(int &v, const char *) {
+        if (fscanf(f, "%i", &v) != 1) throw readfileexception(fn, "File I/O error");
+    }
+    void text(const char *) {}
+};
+struct TextOut {
+    FILE *f;
+    const std::string &fn;
+    void number(double &v, const char *after) { fprintf(f, "%.15le%s", v, after); }
+    void number(int &v, const char *after) { fprintf(f, "%i%s", v, after); }
+    void text(const char *t) { fputs(t, f); }
+};
+
+template <class Codec, size_t N>
+void record(Codec &io, const Slot (&layout)[N], ensemble::Data &d, int sys, int bod, const Counts &c, const char *after_last_triple) {
+    for (const Slot &slot : layout) {
+        const Span s = locate(d, slot.field, sys, bod, c);
+        for (int k = 0; k < s.count; k++) {
+            // the last component of a position or velocity ends its line in the text format
+            const bool ends_triple = (slot.field == F_POS || slot.field == F_VEL) && k == 2;
+            const char *after = ends_triple ? after_last_triple : slot.after;
+            if (s.real)
+                io.number(s.real[k], after);
+            else
+                io.number(s.integer[k], after);
         }
     }
-    fclose(f);
+}
+
+// every record of the file, in file order
+template <class Codec> void all_records(Codec &io, bool text, ensemble::Data &d, const Counts &c) {
+    for (int sys = 0; sys < c.nsys; sys++) {
+        if (text) {
+            record(io, TEXT_SYS, d, sys, 0, c, "");
+            io.text("\n");
+            for (int bod = 0; bod < c.nbod; bod++) {
+                io.text("\t");
+                record(io, TEXT_BODY, d, sys, bod, c, "\n\t");
+                io.text("\n\n");
+            }
+            io.text("\n");
+        } else {
+            record(io, BINARY_SYS, d, sys, 0, c, "");
+            for (int bod = 0; bod < c.nbod; bod++) record(io, BINARY_BODY, d, sys, bod, c, "");
+        }
+    }
+}
+
+struct File { // closes on every way out
+    FILE *f;
+    File(const std::string &fn, const char *mode) : f(fopen(fn.c_str(), mode)) {}
+    ~File() {
+        if (f) fclose(f);
+    }
+};
+
+void check_attribute_counts(const Counts &c, const std::string &fn) {
+    if (c.nsysattr > ensemble::NUM_SYS_ATTRIBUTES)
+        throw readfileexception(fn, "The file requires more system attributes than the library can handle");
+    if (c.nbodattr > ensemble::NUM_BODY_ATTRIBUTES)
+        throw readfileexception(fn, "The file requires more planet attributes than the library can handle");
+}
+
+defaultEnsemble read_file(const std::string &fn, bool text) {
+    File file(fn, text ? "r" : "rb");
+    if (!file.f) throw readfileexception(fn, "cannot open file");
+    Counts c;
+    if (text) {
+        char tag[1024];
+        int version = 0;
+        if (fscanf(file.f, "%1023s %i", tag, &version) != 2 || strcmp(TEXT_TAG, tag) != 0)
+            throw readfileexception(fn, "Invalid file, header doesn't match");
+        if (version != TEXT_VERSION) throw readfileexception(fn, "Incorrect version");
+        if (fscanf(file.f, "%i %i %i %i", &c.nbod, &c.nsys, &c.nsysattr, &c.nbodattr) != 4)
+            throw readfileexception(fn, "Invalid file, header doesn't match");
+    } else {
+        BinaryIn in{file.f, fn};
+        in.number(c.nsys, ""), in.number(c.nbod, ""), in.number(c.nsysattr, ""), in.number(c.nbodattr, "");
+    }
+    check_attribute_counts(c, fn);
+    if (c.nsys < 0 || c.nbod < 0 || c.nsysattr < 0 || c.nbodattr < 0) throw readfileexception(fn, "Invalid file, header doesn't match");
+    hostEnsemble ens = hostEnsemble::create(c.nbod, c.nsys);
+    if (text) {
+        TextIn in{file.f, fn};
+        all_records(in, true, ens.data(), c);
+    } else {
+        BinaryIn in{file.f, fn};
+        all_records(in, false, ens.data(), c);
+    }
     return ens;
 }
 
-static const char *DEFAULT_IO_TAG = "SwarmDataFile";
-static const int CURRENT_IO_VERSION = 2;
-
-defaultEnsemble load_text(const std::string &filename) {
-    FILE *f = fopen(filename.c_str(), "r");
-    if (!f) throw readfileexception(filename, "cannot open file");
-    header h;
-    char tag[1024];
-    int version = 0;
-    if (fscanf(f, "%1023s %i\n", tag, &version) != 2 || strcmp(DEFAULT_IO_TAG, tag) != 0)
-        throw readfileexception(filename, "Invalid file, header doesn't match");
-    if (version != CURRENT_IO_VERSION) throw readfileexception(filename, "Incorrect version");
-    if (fscanf(f, "%i %i %i %i\n\n\n", &h.nbod, &h.nsys, &h.nsysattr, &h.nbodattr) != 4)
-        throw readfileexception(filename, "Invalid file, header doesn't match");
-    if (h.nsysattr > ensemble::NUM_SYS_ATTRIBUTES)
-        throw readfileexception(filename, "The file requires more system attributes than the library can handle");
-    if (h.nbodattr > ensemble::NUM_BODY_ATTRIBUTES)
-        throw readfileexception(filename, "The file requires more planet attributes than the library can handle");
-    hostEnsemble ens = hostEnsemble::create(h.nbod, h.nsys);
-    int ok = 1;
-    for (int i = 0; i < h.nsys && ok; i++) {
-        ensemble::SystemRef sr = ens[i];
-        ok &= fscanf(f, "%i %le %i\n", &sr.id(), &sr.time(), &sr.state()) == 3;
-        for (int l = 0; l < h.nsysattr; l++) ok &= fscanf(f, "%le ", &sr.attribute(l)) == 1;
-        for (int j = 0; j < h.nbod; j++) {
-            ok &= fscanf(f, "\t%le\n\t%le %le %le\n\t%le %le %le\n\n", &sr[j].mass(), &sr[j][0].pos(), &sr[j][1].pos(),
-                         &sr[j][2].pos(), &sr[j][0].vel(), &sr[j][1].vel(), &sr[j][2].vel()) == 7;
-            for (int l = 0; l < h.nbodattr; l++) ok &= fscanf(f, "%le", &sr[j].attribute(l)) == 1;
-        }
+void write_file(defaultEnsemble &ens, const std::string &fn, bool text) {
+    File file(fn, text ? "w" : "wb");
+    if (!file.f) throw writefileexception(fn, "cannot open file");
+    Counts c = {ens.nsys(), ens.nbod(), ensemble::NUM_SYS_ATTRIBUTES, ensemble::NUM_BODY_ATTRIBUTES};
+    if (text) {
+        fprintf(file.f, "%s %i\n%i %i %i %i\n\n\n", TEXT_TAG, TEXT_VERSION, c.nbod, c.nsys, c.nsysattr, c.nbodattr);
+        TextOut out{file.f, fn};
+        all_records(out, true, ens.data(), c);
+    } else {
+        BinaryOut out{file.f, fn};
+        out.number(c.nsys, ""), out.number(c.nbod, ""), out.number(c.nsysattr, ""), out.number(c.nbodattr, "");
+        all_records(out, false, ens.data(), c);
     }
-    fclose(f);
-    if (!ok) throw readfileexception(filename, "File I/O error");
-    return ens;
 }
 
-void save(defaultEnsemble &ens, const std::string &filename) {
-    FILE *f = fopen(filename.c_str(), "wb");
-    if (!f) throw writefileexception(filename, "cannot open file");
-    header h; sys s; body b;
-    memset(&s, 0, sizeof(s));
-    memset(&b, 0, sizeof(b));
-    h.nsys = ens.nsys(), h.nbod = ens.nbod();
-    h.nsysattr = ensemble::NUM_SYS_ATTRIBUTES, h.nbodattr = ensemble::NUM_BODY_ATTRIBUTES;
-    writetoFILE(f, h, filename);
-    for (int i = 0; i < h.nsys; i++) {
-        ensemble::SystemRef sr = ens[i];
-        s.id = sr.id(), s.time = sr.time(), s.state = sr.state();
-        for (int l = 0; l < h.nsysattr; l++) s.attribute[l] = sr.attribute(l);
-        writetoFILE(f, s, filename);
-        for (int j = 0; j < h.nbod; j++) {
-            for (int c = 0; c < 3; c++) b.pos[c] = sr[j][c].pos(), b.vel[c] = sr[j][c].vel();
-            b.mass = sr[j].mass();
-            for (int l = 0; l < h.nbodattr; l++) b.attribute[l] = sr[j].attribute(l);
-            writetoFILE(f, b, filename);
-        }
-    }
-    fclose(f);
-}
+} // namespace
 
-void save_text(defaultEnsemble &ens, const std::string &filename) {
-    FILE *f = fopen(filename.c_str(), "w");
-    if (!f) throw writefileexception(filename, "cannot open file");
-    fprintf(f, "%s %i\n", DEFAULT_IO_TAG, CURRENT_IO_VERSION);
-    fprintf(f, "%i %i %i %i\n\n\n", ens.nbod(), ens.nsys(), ensemble::NUM_SYS_ATTRIBUTES, ensemble::NUM_BODY_ATTRIBUTES);
-    for (int i = 0; i < ens.nsys(); i++) {
-        ensemble::SystemRef sr = ens[i];
-        fprintf(f, "%i %.15le %i\n", sr.id(), sr.time(), sr.state());
-        for (int l = 0; l < ensemble::NUM_SYS_ATTRIBUTES; l++) fprintf(f, "%.15le ", sr.attribute(l));
-        fprintf(f, "\n");
-        for (int j = 0; j < ens.nbod(); j++) {
-            fprintf(f, "\t%.15le\n\t%.15le %.15le %.15le\n\t%.15le %.15le %.15le\n\t", sr[j].mass(), sr[j][0].pos(),
-                    sr[j][1].pos(), sr[j][2].pos(), sr[j][0].vel(), sr[j][1].vel(), sr[j][2].vel());
-            for (int l = 0; l < ensemble::NUM_BODY_ATTRIBUTES; l++) fprintf(f, "%.15le ", sr[j].attribute(l));
-            fprintf(f, "\n\n");
-        }
-        fprintf(f, "\n");
-    }
-    fclose(f);
-}
+defaultEnsemble load(const std::string &filename) { return read_file(filename, false); }
+defaultEnsemble load_text(const std::string &filename) { return read_file(filename, true); }
+void save(defaultEnsemble &ens, const std::string &filename) { write_file(ens, filename, false); }
+void save_text(defaultEnsemble &ens, const std::string &filename) { write_file(ens, filename, true); }
 
 } // namespace snapshot
 
@@ -540,84 +607,97 @@ void set_coordinate_system(const planets_coordinate_system_t &c) { planets_coord
 static bool keplerian_output = false;
 void set_keplerian_output() { keplerian_output = true; }
 
+// Cartesian state about a centre of mass GM -> osculating elements (a, e, i, O, w, M), the conversion the reference's
+// query -k prints (swarm/kepler.h, after Mercury's mco_x2el): the plane from the angular momentum, the conic from the
+// orbital energy, then per conic the eccentricity, the true anomaly `nu` and the mean anomaly.  TINY = 1e-8 decides
+// "in the reference plane", "circular" and "parabolic" as it does there.
+namespace {
+const double TINY = 1.e-8, TWO_PI = 2. * M_PI;
+struct Vec3 {
+    double x, y, z;
+    double dot(const Vec3 &o) const { return x * o.x + y * o.y + z * o.z; }
+    Vec3 cross(const Vec3 &o) const { return Vec3{y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x}; }
+};
+double into_turn(double ang) { return ang < 0. ? ang + TWO_PI : ang; }
+struct InPlane {
+    double e, nu, M; // eccentricity, true anomaly, mean anomaly
+};
+// bound orbit: eccentric anomaly from r = a (1 - e cos E), its quadrant from the sign of r.v
+InPlane on_ellipse(double a, double h2_over_GM, double r, bool inbound, double u) {
+    const double one_minus_p_over_a = 1. - h2_over_GM / a;
+    if (!(one_minus_p_over_a > TINY)) return InPlane{0., u, u}; // circular: anomalies are counted from the node
+    const double e = sqrt(one_minus_p_over_a);
+    const double cosE = (a - r) / (a * e);
+    double E = cosE > 1. ? 0. : (cosE > -1. ? acos(cosE) : M_PI);
+    if (inbound) E = TWO_PI - E;
+    const double denom = 1. - e * cos(E);
+    const double nu = into_turn(atan2(sqrt(1. - e * e) * sin(E) / denom, (cos(E) - e) / denom));
+    return InPlane{e, nu, E - e * sin(E)};
+}
+// unbound orbit: hyperbolic anomaly F from r = a (e cosh F - 1), a > 0 here
+InPlane on_hyperbola(double a, double h2_over_GM, double r, bool inbound) {
+    const double p_over_a = h2_over_GM / a;
+    auto anomaly = [&](double e) {
+        const double coshF = (a + r) / (a * e);
+        return std::log(coshF + sqrt(coshF * coshF - 1.)); // acosh
+    };
+    if (!(p_over_a > TINY)) { // degenerate: a straight line through the centre, e = 1
+        double nu = acos(h2_over_GM / r - 1.);
+        if (inbound) nu = TWO_PI - nu;
+        const double F = anomaly(1.);
+        return InPlane{1., nu, sinh(F) - F};
+    }
+    const double e = sqrt(1. + p_over_a);
+    double F = anomaly(e);
+    if (inbound) F = -F;
+    const double denom = e * cosh(F) - 1.;
+    const double nu = into_turn(atan2(sqrt(e * e - 1.) * sinh(F) / denom, (e - cosh(F)) / denom));
+    return InPlane{e, nu, e * sinh(F) - F};
+}
+} // namespace
+
 void calc_keplerian_for_cartesian(double &a, double &e, double &i, double &O, double &w, double &M, const double x,
                                   const double y, const double z, const double vx, const double vy, const double vz,
                                   const double GM) {
-    const double TINY = 1.e-8, TWOPI = 2. * M_PI;
-    // orbital plane from the angular momentum; u = argument of latitude
-    const double h[3] = {y * vz - z * vy, z * vx - x * vz, x * vy - y * vx};
-    const double h2 = h[0] * h[0] + h[1] * h[1] + h[2] * h[2], hh = sqrt(h2);
-    i = acos(h[2] / hh);
-    double fac = sqrt(h[0] * h[0] + h[1] * h[1]) / hh, u;
-    if (fac < TINY) { // orbit in the reference plane: the node is undefined
+    const Vec3 pos{x, y, z}, vel{vx, vy, vz};
+    const Vec3 h = pos.cross(vel);
+    const double h2 = h.dot(h), hmag = sqrt(h2);
+    i = acos(h.z / hmag);
+    // u = argument of latitude: the angle from the ascending node to the body
+    double u;
+    if (sqrt(h.x * h.x + h.y * h.y) / hmag < TINY) { // orbit in the reference plane: no node, count from +x
         O = 0.;
         u = atan2(y, x);
         if (fabs(i - M_PI) < 10. * TINY) u = -u;
     } else {
-        O = atan2(h[0], -h[1]);
+        O = atan2(h.x, -h.y);
         u = atan2(z / sin(i), x * cos(O) + y * sin(O));
     }
-    if (O < 0.) O += TWOPI;
-    if (u < 0.) u += TWOPI;
-    const double r = sqrt(x * x + y * y + z * z), rdotv = vx * x + vy * y + vz * z;
-    const double energy = (vx * vx + vy * vy + vz * vz) * 0.5 - GM / r;
-    auto wrap = [&](double ang) { // kepler.cpp:141-142
-        if (ang < 0.) ang += TWOPI;
-        return ang - round(ang / TWOPI) * TWOPI;
-    };
-    if (fabs(energy * r / GM) < sqrt(TINY)) { // parabola (kepler.cpp:131-143; its `w` is read before it is set: 0 here)
+    O = into_turn(O);
+    u = into_turn(u);
+    const double r = sqrt(pos.dot(pos));
+    const bool inbound = pos.dot(vel) < 0.;
+    const double energy = vel.dot(vel) * 0.5 - GM / r;
+    InPlane orbit;
+    if (fabs(energy * r / GM) < sqrt(TINY)) {
+        // parabola: a is the pericentre distance.  The reference forms the mean anomaly from its output argument w
+        // before assigning it (kepler.h:133-135 reads `w` where it means the true anomaly); callers pass fresh
+        // variables, which is the value 0 used here, so M = 0 outbound and tan(pi)(1 + ...) inbound -- kept, since
+        // that is what the reference prints.
         a = 0.5 * h2 / GM;
-        e = 1.;
-        const double ww = acos(2. * a / r - 1.);
-        w = 0.;
-        if (rdotv < 0.) w = TWOPI - w;
-        const double tmpf = tan(0.5 * w);
-        M = tmpf * (1. + tmpf * tmpf / 3.);
-        w = wrap(u - ww);
-    } else if (energy < 0) { // ellipse
+        const double half_tan = tan(0.5 * (inbound ? TWO_PI : 0.)); // tan(pi) = -1.2e-16 in doubles, printed as such
+        orbit = InPlane{1., acos(2. * a / r - 1.), half_tan * (1. + half_tan * half_tan / 3.)};
+    } else if (energy < 0) {
         a = -0.5 * GM / energy;
-        fac = 1. - h2 / (GM * a);
-        double ww, cape;
-        if (fac > TINY) {
-            e = sqrt(fac);
-            const double face = (a - r) / (a * e);
-            cape = face > 1. ? 0. : (face > -1. ? acos(face) : M_PI);
-            if (rdotv < 0.) cape = TWOPI - cape;
-            const double cw = (cos(cape) - e) / (1. - e * cos(cape));
-            const double sw = sqrt(1. - e * e) * sin(cape) / (1. - e * cos(cape));
-            ww = atan2(sw, cw);
-            if (ww < 0.) ww += TWOPI;
-        } else {
-            e = 0.;
-            ww = u;
-            cape = u;
-        }
-        M = cape - e * sin(cape);
-        w = wrap(u - ww);
-    } else { // hyperbola (energy > 0; energy == 0 is caught by the parabola test)
+        orbit = on_ellipse(a, h2 / GM, r, inbound, u);
+    } else {
         a = 0.5 * GM / energy;
-        fac = h2 / (GM * a);
-        double ww, capf;
-        if (fac > TINY) {
-            e = sqrt(1. + fac);
-            const double tmpf = (a + r) / (a * e);
-            capf = std::log(tmpf + sqrt(tmpf * tmpf - 1.));
-            if (rdotv < 0.) capf = -capf;
-            const double cw = (e - cosh(capf)) / (e * cosh(capf) - 1.);
-            const double sw = sqrt(e * e - 1.) * sinh(capf) / (e * cosh(capf) - 1.);
-            ww = atan2(sw, cw);
-            if (ww < 0.) ww += TWOPI;
-        } else {
-            e = 1.;
-            double tmpf = 0.5 * h2 / GM;
-            ww = acos(2. * tmpf / r - 1.);
-            if (rdotv < 0.) ww = TWOPI - ww;
-            tmpf = (a + r) / (a * e);
-            capf = std::log(tmpf + sqrt(tmpf * tmpf - 1.));
-        }
-        M = e * sinh(capf) - capf;
-        w = wrap(u - ww);
+        orbit = on_hyperbola(a, h2 / GM, r, inbound);
     }
+    e = orbit.e;
+    M = orbit.M;
+    w = into_turn(u - orbit.nu); // argument of pericentre, folded into (-pi, pi]
+    w -= round(w / TWO_PI) * TWO_PI;
 }
 
 template <typename T> static T arg_parse(const std::string &s) {
@@ -637,16 +717,30 @@ template struct range<int>;
 template struct range<double>;
 
 // one record of the gpulog stream: header {int msgid; int len}, then (double T, int sys, ...)
+// Records with a negative msgid are gpulog's own (MSG_PRINTF = -2: lprintf lines) and carry no (T, sys) heading:
+// their key is (-1, -1), so they sort ahead of every event and `query` lists them with T = -1 (get_Tsys, io.cpp:46-58).
 struct rec_t {
     const char *ptr;
     int len;
     int msgid() const { int v; memcpy(&v, ptr, 4); return v; }
-    double T() const { double v; memcpy(&v, ptr + 8, 8); return v; }
-    int sys() const { int v; memcpy(&v, ptr + 16, 4); return v; }
-    bool operator<(const rec_t &a) const { // idx_t::operator<, io.cpp:72-84
-        double Tt = T(), Ta = a.T();
-        int syst = sys(), sysa = a.sys();
-        return Tt < Ta || (Tt == Ta && (syst < sysa || (syst == sysa && ptr < a.ptr)));
+    bool has_heading() const { return msgid() >= 0 && len >= 20; }
+    double T() const {
+        if (!has_heading()) return -1;
+        double v;
+        memcpy(&v, ptr + 8, 8);
+        return v;
+    }
+    int sys() const {
+        if (!has_heading()) return -1;
+        int v;
+        memcpy(&v, ptr + 16, 4);
+        return v;
+    }
+    bool operator<(const rec_t &a) const { // by time, then system, then position in the file
+        const double Tt = T(), Ta = a.T();
+        if (Tt != Ta) return Tt < Ta;
+        const int st = sys(), sa = a.sys();
+        return st != sa ? st < sa : ptr < a.ptr;
     }
 };
 
@@ -711,6 +805,7 @@ static void record_output_1(std::ostream &out, const rec_t &r, const body_range_
     int sys = r.sys(), flags, nbod;
     memcpy(&flags, r.ptr + 20, 4);
     memcpy(&nbod, r.ptr + 24, 4);
+    if (r.len < 32 || nbod < 0 || 32 + (long long)sizeof(lbody) * nbod > r.len) ERROR("corrupt log record");
     std::vector<lbody> bodies(nbod);
     memcpy((void *)bodies.data(), r.ptr + 32, sizeof(lbody) * nbod);
     lbody center;
@@ -765,6 +860,7 @@ void execute(const std::string &datafile, time_range_t T, sys_range_t sys, body_
         if (r.msgid() == 1)
             record_output_1(out, r, bod);
         else if (r.msgid() == 15 || r.msgid() == 16) { // record_output_15 / _16, query.cpp:243-294
+            if (r.len < 40) ERROR("corrupt log record");
             int body_id;
             double minb, vproj;
             memcpy(&body_id, r.ptr + 20, 4), memcpy(&minb, r.ptr + 24, 8), memcpy(&vproj, r.ptr + 32, 8);
@@ -785,103 +881,107 @@ void execute(const std::string &datafile, time_range_t T, sys_range_t sys, body_
 
 } // namespace query
 
-// ---- utils: swarm/utils.cpp ------------------------------------------------------------------
-hostEnsemble generate_ensemble(config &cfg) { // utils.cpp:63-103
-    int nsys = cfg.require("nsys", 0);
-    int nbod = cfg.require("nbod", 0);
-    double spacing_factor = cfg.optional("spacing_factor", 1.4);
-    double planet_mass = cfg.optional("planet_mass", .0001);
-    double ejection_factor = cfg.optional("ejection_factor", 1.0 / sqrt(2));
-    double star_radius = cfg.optional("star_radius", 0.1);
-    double planet_radius = cfg.optional("planet_radius", 0.001);
+// ---- utils: the helpers of swarm/utils.{hpp,cpp} --------------------------------------------------------------------
+// generate_ensemble (utils.cpp:63-103).  In this fork the generator is deterministic (its random phase is commented
+// out, L89-90), so every system is the same: a unit-mass star at rest at the origin and planets of mass planet_mass on
+// circles (ejection_factor 1/sqrt 2) or faster orbits at r_k = 10 spacing_factor^(k-1), phase k pi/4.  One system is
+// laid out and copied nsys times.
+hostEnsemble generate_ensemble(config &cfg) {
+    const int nsys = cfg.require("nsys", 0), nbod = cfg.require("nbod", 0);
+    const double spacing = cfg.optional("spacing_factor", 1.4), planet_mass = cfg.optional("planet_mass", .0001);
+    const double speed_factor = cfg.optional("ejection_factor", 1.0 / sqrt(2));
+    const double star_radius = cfg.optional("star_radius", 0.1), planet_radius = cfg.optional("planet_radius", 0.001);
+    const double star_mass = 1.;
     hostEnsemble ens = hostEnsemble::create(nbod, nsys);
-    for (int sys = 0; sys < ens.nsys(); ++sys) {
-        double mass_sun = 1.;
-        double x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0;
-        ens.set_body(sys, 0, mass_sun, x, y, z, vx, vy, vz);
-        ens[sys][0].attribute(0) = star_radius;
-        for (int bod = 1; bod < ens.nbod(); ++bod) {
-            double rmag = 10 * pow(spacing_factor, int(bod - 1));
-            double vmag = sqrt(2 * mass_sun / rmag) * ejection_factor;
-            double theta = bod * M_PI / 4; // deterministic in this fork (rand() commented out, L89-90)
-            x = rmag * cos(theta), y = rmag * sin(theta), z = 0;
-            vx = -vmag * sin(theta), vy = vmag * cos(theta), vz = 0.;
-            ens.set_body(sys, bod, planet_mass, x, y, z, vx, vy, vz);
-            ens[sys][bod].attribute(0) = planet_radius;
-        }
-        ens[sys].set_active();
-        ens[sys].time() = 0;
-        ens[sys].id() = sys;
+    if (nsys <= 0 || nbod <= 0) return ens;
+    ensemble::Data &d = ens.data();
+    const size_t nb = nbod, na = ensemble::NUM_BODY_ATTRIBUTES;
+    d.mass[0] = star_mass;
+    d.battr[0] = star_radius;
+    for (size_t k = 1; k < nb; k++) {
+        const double r = 10 * pow(spacing, int(k - 1)), speed = sqrt(2 * star_mass / r) * speed_factor, phase = k * M_PI / 4;
+        const double at[3] = {r * cos(phase), r * sin(phase), 0}, going[3] = {-speed * sin(phase), speed * cos(phase), 0.};
+        for (int c = 0; c < 3; c++) d.pos[k * 3 + c] = at[c], d.vel[k * 3 + c] = going[c];
+        d.mass[k] = planet_mass;
+        d.battr[k * na] = planet_radius;
     }
+    for (size_t sys = 1; sys < (size_t)nsys; sys++) {
+        std::copy(d.pos.begin(), d.pos.begin() + nb * 3, d.pos.begin() + sys * nb * 3);
+        std::copy(d.vel.begin(), d.vel.begin() + nb * 3, d.vel.begin() + sys * nb * 3);
+        std::copy(d.mass.begin(), d.mass.begin() + nb, d.mass.begin() + sys * nb);
+        std::copy(d.battr.begin(), d.battr.begin() + nb * na, d.battr.begin() + sys * nb * na);
+    }
+    for (int sys = 0; sys < nsys; sys++) d.id[sys] = sys; // time 0 and state ACTIVE (0) are create()'s zeros
     return ens;
 }
 
+// |dE/E| of every system between two snapshots of an ensemble, summarised (utils.cpp:108-121)
+ensemble::range_t energy_conservation_error_range(ensemble &ens, ensemble &reference_ensemble) {
+    std::vector<double> before(reference_ensemble.nsys()), after(ens.nsys());
+    reference_ensemble.calc_total_energy(before.data());
+    ens.calc_total_energy(after.data());
+    for (size_t k = 0; k < after.size(); k++) after[k] = fabs((after[k] - before[k]) / before[k]);
+    return ensemble::range_t::calculate(after.begin(), after.end());
+}
 double find_max_energy_conservation_error(ensemble &ens, ensemble &reference_ensemble) {
     return energy_conservation_error_range(ens, reference_ensemble).max;
 }
-ensemble::range_t energy_conservation_error_range(ensemble &ens, ensemble &reference_ensemble) { // utils.cpp:108-121
-    std::vector<double> energy_init(reference_ensemble.nsys()), energy_final(ens.nsys()), deltaE(ens.nsys());
-    reference_ensemble.calc_total_energy(&energy_init[0]);
-    ens.calc_total_energy(&energy_final[0]);
-    for (int sysid = 0; sysid < ens.nsys(); ++sysid)
-        deltaE[sysid] = fabs((energy_final[sysid] - energy_init[sysid]) / energy_init[sysid]);
-    return ensemble::range_t::calculate(deltaE.begin(), deltaE.end());
-}
 
-// utils.cpp:124-138.  The reference rejects nsys > 256000 and nbod > MAX_NBODIES (6 by default);
-// this build accepts what the kernels are instantiated for.
+// utils.cpp:124-138 accepts nsys in [1, 256000] and nbod in [3, MAX_NBODIES]; here the bounds are what the kernels are
+// instantiated for.  A key that is absent counts as the reference's stand-in values (1000 systems, 3 bodies).
 bool validate_configuration(config &cfg) {
-    bool valid = true;
-    int nsystems = cfg.optional("nsys", 1000);
-    int nbodypersystem = cfg.optional("nbod", 3);
-    if (!(nsystems >= 1) || !(nsystems <= (1 << 24))) valid = false;
-    if (!(nbodypersystem >= SWARM_HIP_MIN_NBOD) || !(nbodypersystem <= SWARM_HIP_MAX_NBOD)) valid = false;
-    return valid;
+    const int nsys = cfg.optional("nsys", 1000), nbod = cfg.optional("nbod", 3);
+    return nsys >= 1 && nsys <= (1 << 24) && nbod >= SWARM_HIP_MIN_NBOD && nbod <= SWARM_HIP_MAX_NBOD;
 }
 
-void outputConfigSummary(std::ostream &o, config &cfg) { // utils.cpp:140-150
-    o << "# Integrator:\t" << cfg["integrator"] << "\n"
-      << "# Time step\t" << cfg["time_step"] << "\n"
-      << "# Destination time\t" << cfg["destination_time"] << "\n"
-      << "# Min time step\t" << cfg["min_time_step"] << "\n"
-      << "# Max time step\t" << cfg["max_time_step"] << "\n"
-      << "# No. Systems\t" << cfg["nsys"] << "\n"
-      << "# No. Bodies\t" << cfg["nbod"] << "\n"
-      << std::endl;
+// the "# key<TAB>value" block that heads a benchmark's CSV (utils.cpp:140-150)
+void outputConfigSummary(std::ostream &o, config &cfg) {
+    static const char *const rows[][2] = {{"Integrator:", "integrator"},          {"Time step", "time_step"},
+                                          {"Destination time", "destination_time"}, {"Min time step", "min_time_step"},
+                                          {"Max time step", "max_time_step"},       {"No. Systems", "nsys"},
+                                          {"No. Bodies", "nbod"}};
+    for (const auto &row : rows) o << "# " << row[0] << "\t" << cfg[row[1]] << "\n";
+    o << std::endl;
 }
 
-// utils.cpp:154-162 sets integrator=hermite_cpu although docs/swarm_exec.dox:70-77 documents
-// `hermite`; this build has no CPU integrators, so the documented value is used.
+// `swarm --defaults` (utils.cpp:154-162).  hermite_cpu is the reference's choice; the name is served by the HIP
+// Hermite kernel here (see the plugin table above).
 config default_config() {
     config cfg;
-    cfg["integrator"] = "hermite_cpu"; // utils.cpp:157; served by the HIP Hermite kernel, see REG below
-    cfg["time_step"] = "0.001";
-    cfg["log_writer"] = "null";
-    cfg["nsys"] = "16";
-    cfg["nbod"] = "3";
+    static const char *const defaults[][2] = {
+        {"integrator", "hermite_cpu"}, {"time_step", "0.001"}, {"log_writer", "null"}, {"nsys", "16"}, {"nbod", "3"}};
+    for (const auto &kv : defaults) cfg[kv[0]] = kv[1];
     return cfg;
 }
 
-std::ostream &operator<<(std::ostream &o, const ensemble::range_t &r) { // utils.cpp:163-168
+// "median[min-median,max-median] ", or the median alone when the spread is nil (utils.cpp:163-168)
+std::ostream &operator<<(std::ostream &o, const ensemble::range_t &r) {
     if (r.min - r.max < 1e-11) return o << r.median;
     return o << r.median << "[" << (r.min - r.median) << "," << (r.max - r.median) << "] ";
 }
 
-static inline double square(double x) { return x * x; }
-bool compare_ensembles(ensemble &e1, ensemble &e2, double &pos_diff, double &vel_diff, double &time_diff) { // utils.cpp:170-214
+// The three distances the tool reports (utils.cpp:170-214): the largest Euclidean separation of a body between the two
+// ensembles, in position and in velocity, and the largest relative difference of the systems' times.  Plain
+// reductions over the flat host arrays.
+bool compare_ensembles(ensemble &e1, ensemble &e2, double &pos_diff, double &vel_diff, double &time_diff) {
     if (e1.nsys() != e2.nsys() || e1.nbod() != e2.nbod()) return false;
     pos_diff = vel_diff = time_diff = 0;
-    for (int i = 0; i < e1.nsys(); i++) {
-        for (int j = 0; j < e1.nbod(); j++) {
-            double dp = sqrt(square(e1[i][j][0].pos() - e2[i][j][0].pos()) + square(e1[i][j][1].pos() - e2[i][j][1].pos()) +
-                             square(e1[i][j][2].pos() - e2[i][j][2].pos()));
-            double dv = sqrt(square(e1[i][j][0].vel() - e2[i][j][0].vel()) + square(e1[i][j][1].vel() - e2[i][j][1].vel()) +
-                             square(e1[i][j][2].vel() - e2[i][j][2].vel()));
-            if (dp > pos_diff) pos_diff = dp;
-            if (dv > vel_diff) vel_diff = dv;
+    if (e1.empty() || e2.empty()) return true;
+    const ensemble::Data &a = e1.data(), &b = e2.data();
+    auto largest_separation = [](const std::vector<double> &p, const std::vector<double> &q) {
+        double worst = 0;
+        for (size_t k = 0; k + 2 < p.size(); k += 3) {
+            const double dx = p[k] - q[k], dy = p[k + 1] - q[k + 1], dz = p[k + 2] - q[k + 2];
+            const double sep = sqrt(dx * dx + dy * dy + dz * dz);
+            if (sep > worst) worst = sep;
         }
-        double dt = fabs(e1[i].time() - e2[i].time()) / (e1[i].time() + e2[i].time()) * 2;
-        if (dt > time_diff) time_diff = dt;
+        return worst;
+    };
+    pos_diff = largest_separation(a.pos, b.pos);
+    vel_diff = largest_separation(a.vel, b.vel);
+    for (size_t k = 0; k < a.time.size(); k++) {
+        const double rel = fabs(a.time[k] - b.time[k]) / (a.time[k] + b.time[k]) * 2;
+        if (rel > time_diff) time_diff = rel;
     }
     return true;
 }

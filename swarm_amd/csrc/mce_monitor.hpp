@@ -5,9 +5,9 @@
 //
 // Per step, the lane forms the bounding boxes of its planets' paths (pass_one, L192-219) and the
 // trigger conditions of pass_two on registers with compile-time loops; only when a box pair overlaps
-// or a sun-planet condition holds does it copy the system into a small private work area and run the
-// reference's pass_two (L222-433) literally -- that code swaps its own loop variables (L312), so it
-// needs run-time body indices, which registers cannot give.
+// or a sun-planet condition holds does it copy the system into a small private work area and run
+// pass_two (L222-433) there: the pair scan can be sent back to an earlier row by a merger (McePairScan),
+// so it needs run-time body indices, which registers cannot give.
 #pragma once
 #include "launch.hpp"
 
@@ -31,145 +31,188 @@ struct MceWork {
     int energy_set;
 };
 
-// mce_stat::pass_two, L222-433, thread 0's serial code.  Mixed float/double arithmetic as written
-// in the reference; no FMA contraction.
+// ---- pass_two (monitors/mercury_mce_stat.hpp:222-433), as a scan over planet pairs and one over the planets --------
+// The arithmetic keeps the reference's precision to the letter -- which intermediate is a float, which a double, no
+// FMA contraction -- because a merge decision is a comparison and every printed line and merged mass is checked
+// against the CPU restatement.  The organisation is this file's: what happens to a pair, what happens to a planet
+// near the star, and the order in which pairs are visited are separate pieces.
+
+// smallest squared separation of planets a, b during the step and the time (<= 0, relative to the step's end) at
+// which it is reached: an end point when the pair recedes at the start and approaches at the end, else the minimum
+// of the cubic Hermite interpolant of the squared separation, whose coefficients the reference holds in floats
 template <int N>
-__device__ __noinline__ void mce_pass_two(MceWork<N> &w, const double timestep, const LogBuf lg) {
+__device__ __forceinline__ void mce_closest_approach(const MceWork<N> &w, const int a, const int b, const double h,
+                                                     double &d2min, double &tmin) {
 #pragma clang fp contract(off)
-    int i, j;
-    // planet - planet
-    for (j = 2; j < N; j++)
-        for (i = 1; i < j; i++) {
-            if (w.ne[i][0] >= w.sw[j][0] && w.ne[j][0] >= w.sw[i][0])
-                if (w.ne[i][1] >= w.sw[j][1] && w.ne[j][1] >= w.sw[i][1])
-                    if (w.ne[i][2] >= w.sw[j][2] && w.ne[j][2] >= w.sw[i][2]) {
-                        if (w.m[i] > 0 && w.m[j] > 0) {
-                            const double dx0 = w.p0[i][0] - w.p0[j][0], dy0 = w.p0[i][1] - w.p0[j][1],
-                                         dz0 = w.p0[i][2] - w.p0[j][2];
-                            const double du0 = w.v0[i][0] - w.v0[j][0], dv0 = w.v0[i][1] - w.v0[j][1],
-                                         dw0 = w.v0[i][2] - w.v0[j][2];
-                            const double d0t = (dx0 * du0 + dy0 * dv0 + dz0 * dw0) * 2.0;
-                            const double dx1 = w.p1[i][0] - w.p1[j][0], dy1 = w.p1[i][1] - w.p1[j][1],
-                                         dz1 = w.p1[i][2] - w.p1[j][2];
-                            const double du1 = w.v1[i][0] - w.v1[j][0], dv1 = w.v1[i][1] - w.v1[j][1],
-                                         dw1 = w.v1[i][2] - w.v1[j][2];
-                            const double d1t = (dx1 * du1 + dy1 * dv1 + dz1 * dw1) * 2.0;
-                            const double d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                            const double d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                            double d2min, tmin, tau;
-                            if (d0t > 0 && d1t < 0) {
-                                if (d0 < d1) {
-                                    d2min = d0;
-                                    tmin = -timestep;
-                                } else {
-                                    d2min = d1;
-                                    tmin = 0.0;
-                                }
-                            } else { // Hermite interpolation of the separation; float coefficients (L282-285)
-                                float tmp = (float)(6.0 * (d0 - d1));
-                                const float a = (float)(tmp + 3.0 * timestep * (d0t + d1t));
-                                const float b = (float)(tmp + 2.0 * timestep * (d0t + 2.0 * d1t));
-                                const float c = (float)(timestep * d1t);
-                                tmp = (float)(-0.5 * (b + ((b > 0) ? 1.0 : (-1.0)) * sqrt(fmax((double)(b * b - 4 * a * c), 0.0))));
-                                if (tmp == 0.0)
-                                    tau = 0.0;
-                                else
-                                    tau = c / tmp;
-                                tau = fmin(tau, 0.0);
-                                tau = fmax(tau, -1.0);
-                                tmin = tau * timestep;
-                                tmp = (float)(1.0 + tau);
-                                d2min = tau * tau * ((3.0 + 2.0 * tau) * d0 + tmp * timestep * d0t) +
-                                        tmp * tmp * ((1.0 - 2.0 * tau) * d1 + tau * timestep * d1t);
-                                d2min = fmax(d2min, 0.0);
-                            }
-                            float d2hit = (float)fmax(w.rphys[i], w.rphys[j]);
-                            d2hit = d2hit * d2hit;
-                            if (d2min <= d2hit) {
-                                if (w.m[i] < w.m[j]) { // L312 swaps the loop variables themselves
-                                    const int k = i;
-                                    i = j;
-                                    j = k;
-                                }
-                                SWH_LPRINTF(lg, "Hitting detected: sysid = %d, i = %d, j = %d, time= %f\n", parg(w.id),
-                                            parg(i), parg(j), parg(w.t + tmin));
-                                const float msum = (float)(w.m[i] + w.m[j]);
-                                const float mredu = (float)(w.m[i] * w.m[j] / msum);
-                                w.energy_lost = 0.5 * mredu * (du1 * du1 + dv1 * dv1 + dw1 * dw1) -
-                                                w.m[i] * w.m[j] / sqrt(dx1 * dx1 + dy1 * dy1 + dz1 * dz1);
-                                w.energy_set = 1;
-                                const float tmp1 = (float)(w.m[i] / msum);
-                                const float tmp2 = (float)(w.m[j] / msum);
-                                for (int c = 0; c < 3; c++) {
-                                    w.p1[i][c] = w.p1[i][c] * tmp1 + w.p1[j][c] * tmp2;
-                                    w.v1[i][c] = w.v1[i][c] * tmp1 + w.v1[j][c] * tmp2;
-                                }
-                                w.m[i] = msum;
-                                for (int c = 0; c < 3; c++) {
-                                    w.p1[j][c] *= 100;
-                                    w.v1[j][c] = 0.0;
-                                }
-                                w.m[j] = 0.0;
-                            }
-                        } else {
-                            SWH_LPRINTF(lg, "3 planets in collision: System halted ! T=%f\n", parg(w.t));
-                            uint8_t *r = log_reserve_lane(lg, snapshot_len(N));
-                            if (r) snapshot_fill<N>(r, w.t, w.id, w.state, w.p1, w.v1, w.m);
-                            w.state = SWARM_HIP_DISABLED;
-                        }
-                    }
-        }
-    // sun - planet
-    i = 0;
-    for (j = 1; j < N; j++) {
-        const float rr0 = (float)(w.p0[j][0] * w.p0[j][0] + w.p0[j][1] * w.p0[j][1] + w.p0[j][2] * w.p0[j][2]);
-        const float rr1 = (float)(w.p1[j][0] * w.p1[j][0] + w.p1[j][1] * w.p1[j][1] + w.p1[j][2] * w.p1[j][2]);
-        const float rv0 = (float)(w.v0[j][0] * w.p0[j][0] + w.v0[j][1] * w.p0[j][1] + w.v0[j][2] * w.p0[j][2]);
-        // L361: the z term is pos*pos in the reference
-        const float rv1 = (float)(w.v1[j][0] * w.p1[j][0] + w.v1[j][1] * w.p1[j][1] + w.p1[j][2] * w.p1[j][2]);
-        if ((rv0 * timestep <= -1e-6 && rv1 * timestep >= 1e-6) || (fminf(rr0, rr1) <= w.radius0 * w.radius0)) {
-            if (w.m[j] > 0) {
-                const float hx = (float)(w.p0[j][1] * w.v0[j][2] - w.p0[j][2] * w.v0[j][1]);
-                const float hy = (float)(w.p0[j][2] * w.v0[j][0] - w.p0[j][0] * w.v0[j][2]);
-                const float hz = (float)(w.p0[j][0] * w.v0[j][1] - w.p0[j][1] * w.v0[j][0]);
-                const float v2 = (float)(w.v0[j][0] * w.v0[j][0] + w.v0[j][1] * w.v0[j][1] + w.v0[j][2] * w.v0[j][2]);
-                const float h2 = hx * hx + hy * hy + hz * hz;
-                const float p = (float)(h2 / (w.m[i] + w.m[j]));
-                const float r0 = sqrtf(rr0);
-                const float temp = (float)(1.0 + p * (v2 / (w.m[i] + w.m[j]) - 2.0 / r0));
-                const float e = (float)sqrt(fmax((double)temp, 0.0));
-                const float q = (float)(p / (1.0 + e));
-                if (q <= w.radius0) {
-                    SWH_LPRINTF(lg, "Hitting with the sun detected: sysid = %d, time = %f, j=%d\n", parg(w.id), parg(w.t),
-                                parg(j));
-                    const float tmp2 = (float)(w.m[j] / (w.m[j] + w.m[i]));
-                    for (int c = 0; c < 3; c++) {
-                        w.p1[i][c] = tmp2 * w.p1[j][c];
-                        w.v1[i][c] = tmp2 * w.v1[j][c];
-                    }
-                    w.m[i] = w.m[j] + w.m[i];
-                    for (int c = 0; c < 3; c++) {
-                        w.p1[j][c] *= 100.0;
-                        w.v1[j][c] *= 0.0;
-                    }
-                    w.m[j] = 0.0;
-                    for (int k = 1; k < N; k++)
-                        if (k != j)
-                            for (int c = 0; c < 3; c++) {
-                                w.p1[k][c] = w.p1[k][c] - w.p1[0][c];
-                                w.v1[k][c] = w.v1[k][c] - w.v1[0][c];
-                            }
-                }
-            } else {
-                const PArg none[1] = {parg(0)};
-                const char f[] = "2 planets and the sun in collision: System halted !\n";
-                log_printf_lane(lg, f, (int)sizeof(f), none, 0);
-                uint8_t *r = log_reserve_lane(lg, snapshot_len(N));
-                if (r) snapshot_fill<N>(r, w.t, w.id, w.state, w.p1, w.v1, w.m);
-                w.state = SWARM_HIP_DISABLED;
-            }
+    double sep[2] = {0, 0}, rate[2] = {0, 0}; // |dr|^2 and d|dr|^2/dt at the start [0] and the end [1] of the step
+    {
+        const double rx = w.p0[a][0] - w.p0[b][0], ry = w.p0[a][1] - w.p0[b][1], rz = w.p0[a][2] - w.p0[b][2];
+        const double ux = w.v0[a][0] - w.v0[b][0], uy = w.v0[a][1] - w.v0[b][1], uz = w.v0[a][2] - w.v0[b][2];
+        rate[0] = (rx * ux + ry * uy + rz * uz) * 2.0;
+        sep[0] = rx * rx + ry * ry + rz * rz;
+    }
+    {
+        const double rx = w.p1[a][0] - w.p1[b][0], ry = w.p1[a][1] - w.p1[b][1], rz = w.p1[a][2] - w.p1[b][2];
+        const double ux = w.v1[a][0] - w.v1[b][0], uy = w.v1[a][1] - w.v1[b][1], uz = w.v1[a][2] - w.v1[b][2];
+        rate[1] = (rx * ux + ry * uy + rz * uz) * 2.0;
+        sep[1] = rx * rx + ry * ry + rz * rz;
+    }
+    if (rate[0] > 0 && rate[1] < 0) {
+        const bool at_start = sep[0] < sep[1];
+        d2min = at_start ? sep[0] : sep[1];
+        tmin = at_start ? -h : 0.0;
+        return;
+    }
+    // stationary point of the interpolant: root of qa tau^2 + qb tau + qc, tau in [-1, 0] (L282-295)
+    const float six_drop = (float)(6.0 * (sep[0] - sep[1]));
+    const float qa = (float)(six_drop + 3.0 * h * (rate[0] + rate[1]));
+    const float qb = (float)(six_drop + 2.0 * h * (rate[0] + 2.0 * rate[1]));
+    const float qc = (float)(h * rate[1]);
+    const float root_den = (float)(-0.5 * (qb + ((qb > 0) ? 1.0 : (-1.0)) * sqrt(fmax((double)(qb * qb - 4 * qa * qc), 0.0))));
+    double tau = (root_den == 0.0) ? 0.0 : qc / root_den;
+    tau = fmax(fmin(tau, 0.0), -1.0);
+    tmin = tau * h;
+    const float one_plus_tau = (float)(1.0 + tau);
+    d2min = tau * tau * ((3.0 + 2.0 * tau) * sep[0] + one_plus_tau * h * rate[0]) +
+            one_plus_tau * one_plus_tau * ((1.0 - 2.0 * tau) * sep[1] + tau * h * rate[1]);
+    d2min = fmax(d2min, 0.0);
+}
+
+// inelastic merger of two planets at the end of the step: `keep` takes the total mass and the mass-weighted position
+// and velocity (weights in float), `gone` is left massless, at rest, a hundred times farther out; the orbital energy
+// of the pair goes to the system's attribute 0 (L316-336)
+template <int N>
+__device__ __forceinline__ void mce_merge_planets(MceWork<N> &w, const int keep, const int gone) {
+#pragma clang fp contract(off)
+    const double rx = w.p1[keep][0] - w.p1[gone][0], ry = w.p1[keep][1] - w.p1[gone][1], rz = w.p1[keep][2] - w.p1[gone][2];
+    const double ux = w.v1[keep][0] - w.v1[gone][0], uy = w.v1[keep][1] - w.v1[gone][1], uz = w.v1[keep][2] - w.v1[gone][2];
+    const float total = (float)(w.m[keep] + w.m[gone]);
+    const float reduced = (float)(w.m[keep] * w.m[gone] / total);
+    w.energy_lost = 0.5 * reduced * (ux * ux + uy * uy + uz * uz) - w.m[keep] * w.m[gone] / sqrt(rx * rx + ry * ry + rz * rz);
+    w.energy_set = 1;
+    const float share_keep = (float)(w.m[keep] / total), share_gone = (float)(w.m[gone] / total);
+    for (int c = 0; c < 3; c++) {
+        w.p1[keep][c] = w.p1[keep][c] * share_keep + w.p1[gone][c] * share_gone;
+        w.v1[keep][c] = w.v1[keep][c] * share_keep + w.v1[gone][c] * share_gone;
+        w.p1[gone][c] *= 100;
+        w.v1[gone][c] = 0.0;
+    }
+    w.m[keep] = total;
+    w.m[gone] = 0.0;
+}
+
+// a third body in a collision: report, snapshot, disable -- and go on scanning, as the reference does
+template <int N>
+__device__ __forceinline__ void mce_halt(MceWork<N> &w, const LogBuf &lg) {
+    uint8_t *r = log_reserve_lane(lg, snapshot_len(N));
+    if (r) snapshot_fill<N>(r, w.t, w.id, w.state, w.p1, w.v1, w.m);
+    w.state = SWARM_HIP_DISABLED;
+}
+
+template <int N>
+__device__ __forceinline__ bool mce_boxes_overlap(const MceWork<N> &w, const int a, const int b) {
+    for (int c = 0; c < 3; c++)
+        if (!(w.ne[a][c] >= w.sw[b][c] && w.ne[b][c] >= w.sw[a][c])) return false;
+    return true;
+}
+
+// The order in which the reference visits planet pairs (lo, hi), 1 <= lo < hi < N: row by row, hi = 2 .. N-1, lo =
+// 1 .. hi-1.  One irregularity is part of its observable behaviour: when the body with the LOWER index is the lighter
+// one of a merging pair, the reference exchanges its two loop variables to name the survivor first (L312) and never
+// exchanges them back, so its loops resume from row lo + 1: every pair of the rows lo+1 .. hi is visited again, with
+// the boxes of the step's start and the absorbed body now massless -- which is how such a merger ends in "3 planets
+// in collision: System halted" whenever the absorbed body's box still overlaps a neighbour's.  `rewind_after` is
+// that irregularity, spelled out.
+struct McePairScan {
+    int lo, hi;
+    __device__ McePairScan() : lo(1), hi(2) {}
+    __device__ bool done(const int n) const { return hi >= n; }
+    __device__ void next() {
+        if (++lo >= hi) lo = 1, ++hi;
+    }
+    // the next() that follows lands on the first pair of row absorbed_lower_index + 1
+    __device__ void rewind_after(const int absorbed_lower_index) { lo = hi = absorbed_lower_index; }
+};
+
+// planet j against the star over the step (L352-429): a pericentre passage (r.v changes sign from inward to outward)
+// or a start/end point inside the star's radius; then, from the osculating orbit at the step's start in float
+// arithmetic, accretion when the pericentre distance q = p / (1 + e) is inside the star
+template <int N>
+__device__ __forceinline__ void mce_planet_and_star(MceWork<N> &w, const int j, const double h, const LogBuf &lg) {
+#pragma clang fp contract(off)
+    const int star = 0;
+    const double(&x0)[3] = w.p0[j], (&u0)[3] = w.v0[j], (&x1)[3] = w.p1[j], (&u1)[3] = w.v1[j];
+    const float r2_start = (float)(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]);
+    const float r2_end = (float)(x1[0] * x1[0] + x1[1] * x1[1] + x1[2] * x1[2]);
+    const float rdotv_start = (float)(u0[0] * x0[0] + u0[1] * x0[1] + u0[2] * x0[2]);
+    const float rdotv_end = (float)(u1[0] * x1[0] + u1[1] * x1[1] + x1[2] * x1[2]); // L361: z term is pos*pos there
+    const bool pericentre_passed = rdotv_start * h <= -1e-6 && rdotv_end * h >= 1e-6;
+    if (!pericentre_passed && !(fminf(r2_start, r2_end) <= w.radius0 * w.radius0)) return;
+    if (!(w.m[j] > 0)) { // an absorbed body falling in as well
+        const PArg none[1] = {parg(0)};
+        const char f[] = "2 planets and the sun in collision: System halted !\n";
+        log_printf_lane(lg, f, (int)sizeof(f), none, 0);
+        mce_halt(w, lg);
+        return;
+    }
+    const float hx = (float)(x0[1] * u0[2] - x0[2] * u0[1]);
+    const float hy = (float)(x0[2] * u0[0] - x0[0] * u0[2]);
+    const float hz = (float)(x0[0] * u0[1] - x0[1] * u0[0]);
+    const float speed2 = (float)(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+    const float h2 = hx * hx + hy * hy + hz * hz;
+    const double gm = w.m[star] + w.m[j];
+    const float semilatus = (float)(h2 / gm);
+    const float r_start = sqrtf(r2_start);
+    const float ecc2 = (float)(1.0 + semilatus * (speed2 / gm - 2.0 / r_start));
+    const float ecc = (float)sqrt(fmax((double)ecc2, 0.0));
+    const float pericentre = (float)(semilatus / (1.0 + ecc));
+    if (!(pericentre <= w.radius0)) return;
+    SWH_LPRINTF(lg, "Hitting with the sun detected: sysid = %d, time = %f, j=%d\n", parg(w.id), parg(w.t), parg(j));
+    // the star takes the planet's momentum share and mass; the planet is parked like an absorbed one; the other
+    // planets are re-centred on the displaced star (L405-423)
+    const float planet_share = (float)(w.m[j] / (w.m[j] + w.m[star]));
+    for (int c = 0; c < 3; c++) {
+        w.p1[star][c] = planet_share * x1[c];
+        w.v1[star][c] = planet_share * u1[c];
+    }
+    w.m[star] = w.m[j] + w.m[star];
+    for (int c = 0; c < 3; c++) {
+        w.p1[j][c] *= 100.0;
+        w.v1[j][c] *= 0.0;
+    }
+    w.m[j] = 0.0;
+    for (int k = 1; k < N; k++) {
+        if (k == j) continue;
+        for (int c = 0; c < 3; c++) {
+            w.p1[k][c] = w.p1[k][c] - w.p1[star][c];
+            w.v1[k][c] = w.v1[k][c] - w.v1[star][c];
         }
     }
+}
+
+template <int N>
+__device__ __noinline__ void mce_pass_two(MceWork<N> &w, const double timestep, const LogBuf lg) {
+    for (McePairScan scan; !scan.done(N); scan.next()) {
+        const int lo = scan.lo, hi = scan.hi;
+        if (!mce_boxes_overlap(w, lo, hi)) continue;
+        if (!(w.m[lo] > 0 && w.m[hi] > 0)) { // one of the two was absorbed earlier in this pass
+            SWH_LPRINTF(lg, "3 planets in collision: System halted ! T=%f\n", parg(w.t));
+            mce_halt(w, lg);
+            continue;
+        }
+        double d2min, tmin;
+        mce_closest_approach(w, lo, hi, timestep, d2min, tmin);
+        float reach = (float)fmax(w.rphys[lo], w.rphys[hi]);
+        reach = reach * reach;
+        if (!(d2min <= reach)) continue;
+        const bool lower_is_lighter = w.m[lo] < w.m[hi];
+        const int keep = lower_is_lighter ? hi : lo, gone = lower_is_lighter ? lo : hi;
+        SWH_LPRINTF(lg, "Hitting detected: sysid = %d, i = %d, j = %d, time= %f\n", parg(w.id), parg(keep), parg(gone),
+                    parg(w.t + tmin));
+        mce_merge_planets(w, keep, gone);
+        if (lower_is_lighter) scan.rewind_after(lo);
+    }
+    for (int j = 1; j < N; j++) mce_planet_and_star(w, j, timestep, lg);
 }
 
 // rce (attribute 1), rphysics (attribute 2) of every body and the star's radius (attribute 0 of body 0)

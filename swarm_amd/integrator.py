@@ -93,7 +93,9 @@ class BinaryWriter:
         raw = open(self.rawfn, "rb").read()[96:]
         recs = []
         for pos, (msgid, rec) in enumerate(gpulog.records(raw)):
-            t, s = struct.unpack_from("<di", rec, 8)
+            # gpulog's own records (msgid < 0: lprintf lines) have no (T, sys) heading and sort first
+            # with the key (-1, -1), swarm/log/io.cpp:46-58
+            t, s = struct.unpack_from("<di", rec, 8) if (msgid >= 0 and len(rec) >= 20) else (-1.0, -1)
             recs.append((t, s, pos, rec))
         recs.sort(key=lambda r: r[:3])
         with open(self.binfn, "wb") as out:
@@ -336,6 +338,8 @@ class GpuIntegrator(Integrator):
         attempts = 0
         for _ in range(self._max_attempts):
             self.launch_integrator()
+            if self.stream:     # the flush reads and clears the cursor on the null stream: let the launch stream drain first
+                capi.check(capi.lib.swarm_hip_synchronize(self.stream))
             self._logman.flush()
             attempts += 1
             if self._dens.count_active(self.stream) == 0:

@@ -108,6 +108,50 @@ def test_query_reproduces_reference_bdb_golden(tmp_path, oracle):
         assert abs(a - 1.4 ** (int(r[3]) - 1)) < 0.02 and e < 0.02 and inc == 0.0
 
 
+def test_printf_records_sort_first_and_query_prints_them_with_T_minus_one(tmp_path, oracle):
+    """gpulog's own records (msgid < 0: the lprintf lines of verbose_on_*, mce_stat's reports) have no (T, sys)
+    heading; the reference keys them (-1, -1) (swarm/log/io.cpp:46-58), so they come first in a T-sorted file and
+    `swarm query` lists them as T = -1, sys = -1.  Two printf records are planted in the middle and at the end of a
+    snapshot stream; both the C++ ordering (`swarm query` on the raw file) and the Python binary writer's sort put
+    them first, in file order, and produce the same listing."""
+    import struct
+    import swarm_amd as S
+    O = oracle
+    e = O.load_text(os.path.join(GOLDEN, "bdb", "test.4.in.txt"))
+    log = O.Log(1 << 20)
+    O.integrate(e, O.params("hermite_cpu", 0.3, time_step=0.01), O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), log)
+    snaps = log.bytes()
+
+    def lprintf(fmt, value):                 # header | char fmt[n] (NUL included) | int32 at 4-byte alignment | pad to 16
+        body = fmt.encode() + b"\0"
+        body += b"\0" * (-(8 + len(body)) % 4) + struct.pack("<i", value)
+        ln = (8 + len(body) + 15) // 16 * 16
+        return struct.pack("<ii", -2, ln) + body.ljust(ln - 8, b"\0")
+    first, second = lprintf("Orbit is odd: sys=%d\n", 7), lprintf("and again: %d\n", 9)
+    half = 288 * (len(snaps) // 288 // 2)
+    stream = snaps[:half] + first + snaps[half:] + second
+    raw = tmp_path / "v.bin.raw"
+    raw.write_bytes(swarm_header("unsorted") + stream)
+    lines = run("query", "-f", raw).stdout.splitlines()
+    assert lines[0].split() == ["-2", "-1", "-1"] and lines[1].split() == ["-2", "-1", "-1"]
+    assert all(l.split()[0] == "1" for l in lines[2:] if l.strip())
+    # the Python writer: same records first, in file order, then the snapshots by (T, sys)
+    w = S.integrator.BinaryWriter(S.config({"log_output": str(tmp_path / "py.bin")}))
+    w.process(stream)
+    w.close()
+    blob = open(tmp_path / "py.bin", "rb").read()
+    assert blob[:96] == swarm_header("sorted", len(stream)) and blob[96:96 + len(first) + len(second)] == first + second
+    keys = [(r["time"], r["sys"]) for r in O.parse_log(blob[96 + len(first) + len(second):])]
+    assert keys == sorted(keys) and len(keys) == len(snaps) // 288
+    assert run("query", "-f", tmp_path / "py.bin").stdout.splitlines() == lines
+    # a truncated snapshot record is refused, not read past its end (record_output_1)
+    bad = bytearray(snaps[:288])
+    struct.pack_into("<i", bad, 24, 1000)                       # nbod = 1000 in a 288-byte record
+    (tmp_path / "bad.raw").write_bytes(swarm_header("unsorted") + bytes(bad))
+    p = run("query", "-f", tmp_path / "bad.raw", check=False)
+    assert p.returncode == 1 and "corrupt log record" in p.stderr
+
+
 # ---------------------------------------------------------------- GPU side
 CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-8),
          ("irk2", 1e-8)]
