@@ -364,7 +364,17 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
     unsigned long long steps = 0;
     const double dest = ip.destination_time;
 
-    if (s.state == SWARM_HIP_ACTIVE) {
+    // The wave goes through the step loop whole, until its last system is done: a lane with nothing (left) to do takes
+    // steps of h = 0, which leave its registers exactly as they are, instead of leaving the loop.  MI355X issues FP64
+    // VALU instructions at less than a third of the rate once 8 or fewer lanes of a wavefront are enabled
+    // (tools/ubench_exec.hip), so a wave thinned out by ejections or by different start times would crawl.
+    // Done (WHOLE) where waves do thin out: with a monitor armed (ejections, close encounters) and for Verlet's
+    // per-system step; with nothing to monitor every lane of a fixed-step propagator takes the same steps unless
+    // start times differ, and the selects cost the uniform case 3 % (C4 shard 10.76 -> 11.11 ms).
+    constexpr bool WHOLE = MON != MON_OFF || KIND == SWARM_HIP_VERLET;
+    const bool mine = s.state == SWARM_HIP_ACTIVE; // only these systems are converted, integrated and stored
+    if (WHOLE ? __any(mine) : mine) {
+        bool live = mine;
         MonState ms;
         mon_init(ms, s);
         double acc[N][3];
@@ -387,14 +397,14 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
             hk.set(ip.time_step);
         }
 
-        for (int iter = 0; iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; iter++) {
+        for (int iter = 0; iter < ip.max_iterations && (WHOLE ? __any(live) : live); iter++) {
             double max_timestep;
             {
 #pragma clang fp contract(off)
                 max_timestep = dest - s.t;
             }
             if (KIND == SWARM_HIP_MVS) { // MVSPropagator::advance, mvs.hpp:260-293
-                const double hby2 = 0.5 * fmin(max_timestep, ip.time_step);
+                const double hby2 = (!WHOLE || live) ? 0.5 * fmin(max_timestep, ip.time_step) : 0.0;
                 mvs_drift(s, hby2, inv_m0);
 #pragma unroll
                 for (int b = 1; b < N; b++)
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 mvs_drift(s, hby2, inv_m0);
                 s.t += 2.0 * hby2;
             } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
-                const double h = fmin(ip.time_step, max_timestep);
+                const double h = (!WHOLE || live) ? fmin(ip.time_step, max_timestep) : 0.0;
                 if (h != hk.h) hk.set(h);
                 hermite_step<N>(s, hk, acc, hj, ha1, hj1);
 #pragma unroll
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     for (int c = 0; c < 3; c++) acc[b][c] = ha1[b][c], hj[b][c] = hj1[b][c];
                 s.t += h;
             } else if (KIND == SWARM_HIP_EULER) { // EulerPropagator::advance, euler.hpp:101-122
-                const double h = fmin(ip.time_step, max_timestep);
+                const double h = (!WHOLE || live) ? fmin(ip.time_step, max_timestep) : 0.0;
                 const double third = 1.0 / 3.0;
                 double jerk[N][3];
                 accjerk<N>(s.p, s.v, s.m, acc, jerk);
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     }
                 s.t += h;
             } else if (KIND == SWARM_HIP_VERLET) { // VerletPropagator::advance, verlet.hpp:139-175
-                const double h = timestep;
+                const double h = (!WHOLE || live) ? timestep : 0.0;
                 const double h_first_half = 0.5 * h;
 #pragma unroll
                 for (int b = 0; b < N; b++)
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     for (int c = 0; c < 3; c++) s.p[b][c] = s.p[b][c] + h_first_half * s.v[b][c];
                 acc_only<N, false>(s.p, s.m, acc);
                 timestep = verlet_timestep(s, ip);
-                const double h_second_half = 0.5 * timestep;
+                const double h_second_half = (!WHOLE || live) ? 0.5 * timestep : 0.0;
 #pragma unroll
                 for (int b = 0; b < N; b++)
 #pragma unroll
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     }
                 s.t += h_first_half + h_second_half;
             } else { // MidpointPropagator::advance, midpoint.hpp:106-160
-                const double H = fmin(max_timestep, ip.time_step);
+                const double H = (!WHOLE || live) ? fmin(max_timestep, ip.time_step) : 0.0;
                 const int n = 4;
                 const double h = H / n;
                 double p_i[N][3], p_im1[N][3], p_im2[N][3], v_i[N][3], v_im1[N][3], v_im2[N][3];
@@ -497,11 +507,13 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     }
                 s.t += H;
             }
-            steps++;
+            if (!WHOLE || live) steps++;
 
             // monitor (generic_gpu_bppt_integrator.hpp:189-224): pass_one in internal coordinates,
             // standard coordinates only for a system that is about to be logged.
-            if (MON == MON_ON) {
+            if (WHOLE && !live) {
+                // nothing to monitor for a lane that stands still
+            } else if (MON == MON_ON) {
                 // stop_on_ejection / log_time_interval: wave-uniform early-out here, the monitor proper out of line
                 // (generic_mon_call); the close-encounter composite is launched as MON_VERBOSE and stays inline
                 bool maybe = false;
@@ -532,11 +544,12 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     if (__any(want)) log_system(lg, s, want);
                 if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_internal(s);
             }
-            if (s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
+            if ((!WHOLE || live) && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
+            live = live && s.state == SWARM_HIP_ACTIVE;
         }
         // prop.shutdown()
         if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
-        store_state(e, gid, s);
+        if (mine) store_state(e, gid, s);
     }
     if (cnt.accepted) cnt.accepted[gid] += steps;
     if (cnt.attempted) cnt.attempted[gid] += steps;

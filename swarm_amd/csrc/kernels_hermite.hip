@@ -45,7 +45,11 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
 
     unsigned long long steps = 0;
-    if (s.state == SWARM_HIP_ACTIVE) {
+    // WHOLE: the wave is kept whole through ragged ends (general loop below).  Not for the fixed-step kernel with
+    // nothing to monitor -- Hermite.cfg as shipped, the headline: its lanes all take the same steps unless their start
+    // times differ, and the extra control flow cost that kernel 3 % (16.88 -> 17.38 ms, A/B on one box).
+    constexpr bool WHOLE = ADAPTIVE || MON != MON_OFF;
+    if (WHOLE ? __any(s.state == SWARM_HIP_ACTIVE) : (s.state == SWARM_HIP_ACTIVE)) {
         double fa[2][N][3], fj[2][N][3]; // ping-pong force buffers
         accjerk<N>(s.p, s.v, s.m, fa[0], fj[0]);
         const double dest = ip.destination_time;
@@ -53,9 +57,11 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         k.set(ip.time_step);
 
         // everything of a step after h is known: step, time, monitor, end test
+        // `on` = this lane really takes the step; a lane that only keeps the wave whole comes with h = 0
         auto finish_step = [&](const double h, const double (&a0)[N][3], const double (&j0)[N][3],
-                               double (&a1)[N][3], double (&j1)[N][3]) {
+                               double (&a1)[N][3], double (&j1)[N][3], const bool on) {
             hermite_step<N>(s, k, a0, j0, a1, j1);
+            if (!on) return;
             s.t += h;
             steps++;
             if (MON == MON_TRANSIT)
@@ -117,10 +123,13 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
                 return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE && !(s.t + dt > dest);
             };
             while (full()) {
-                finish_step(dt, fa[0], fj[0], fa[1], fj[1]);
+                // a wave thinned out to 8 lanes or fewer (ejections, different start times) would run its FP64
+                // instructions at a third of the rate: hand the stragglers to the general loop, which keeps the wave whole
+                if (WHOLE && __popcll(__ballot(true)) <= 8) break;
+                finish_step(dt, fa[0], fj[0], fa[1], fj[1], true);
                 iter++;
                 if (full()) {
-                    finish_step(dt, fa[1], fj[1], fa[0], fj[0]);
+                    finish_step(dt, fa[1], fj[1], fa[0], fj[0], true);
                     iter++;
                 } else {
 #pragma unroll
@@ -130,8 +139,14 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
                 }
             }
         }
-        // General loop: per-step h (adaptive step, or the clipped final step of the fixed-step form)
-        while (iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE) {
+        // General loop: per-step h (adaptive step, or the clipped final step of the fixed-step form).
+        // The wave stays whole until its last system is done: a lane with nothing left to do takes steps of h = 0,
+        // which leave its registers exactly as they are (every corrector weight is 0, p + 0 = p), instead of leaving
+        // the loop -- MI355X issues FP64 VALU instructions at less than a third of the rate once 8 or fewer lanes of a
+        // wavefront are enabled (tools/ubench_exec.hip), so a thinned-out wave would crawl through its tail.
+        auto live = [&]() { return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; };
+        while (WHOLE ? __any(live()) : live()) {
+            const bool on = !WHOLE || live();
             double h;
             if (ADAPTIVE) {
                 // calc_adaptive_time_step, hermite_adap.hpp:69-98: sum over bodies of |jerk|^2/|acc|^2
@@ -153,9 +168,10 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
                 if (s.t + h > dest) h = dest - s.t;
             }
-            k.template set<ADAPTIVE>(h);
-            finish_step(h, fa[0], fj[0], fa[1], fj[1]);
-            iter++;
+            if (WHOLE && !on) h = 0.0;
+            if (ADAPTIVE || !WHOLE || h != k.h) k.template set<ADAPTIVE>(h);
+            finish_step(h, fa[0], fj[0], fa[1], fj[1], on);
+            if (on) iter++;
 #pragma unroll
             for (int b = 0; b < N; b++)
 #pragma unroll

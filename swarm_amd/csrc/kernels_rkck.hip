@@ -74,12 +74,22 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
     double time_step = ip.max_time_step; // L133
     unsigned long long accepted = 0, attempted = 0;
 
-    for (int iter = 0; iter < iteration_count && s.state == SWARM_HIP_ACTIVE; iter++) {
+    // The wave stays whole: every lane goes through every attempt until the LAST system of the wave is done, and a
+    // lane that is done (or was not ACTIVE at launch) simply never commits -- its registers keep the state that is
+    // stored at the end.  Leaving the loop lane by lane would thin the wave out, and MI355X issues FP64 VALU
+    // instructions at less than a third of the rate once 8 or fewer lanes of a wavefront are enabled (measured,
+    // tools/ubench_exec.hip: 5.3 cycles per instruction with 9..64 lanes enabled, 16.9 with 1..8, whichever lanes they
+    // are).  A tail of a few slow systems per wave -- the normal end of an adaptive run -- ran 4.4x slower per attempt.
+    bool live = s.state == SWARM_HIP_ACTIVE;
+    for (int iter = 0; iter < iteration_count && __any(live); iter++) {
         double h = time_step;
         {
 #pragma clang fp contract(off)
             if (s.t + h > dest) h = dest - s.t;
         }
+        // fixed step: every attempt is committed, so a lane that only keeps the wave whole takes h = 0, which leaves
+        // its registers exactly as they are (p + 0 * (...) = p); the adaptive form withholds the commit instead
+        if (!ADAPTIVE && !live) h = 0.0;
         double ka[6][N][3];
         double sp[N][3];
 #pragma unroll
@@ -175,26 +185,28 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
             accept_step = (normalized_error < 1.0) || (fabs(time_step - new_time_step) < 1e-10);
             time_step = new_time_step;
         }
-        attempted++;
+        if (ADAPTIVE) accept_step = accept_step && live;
+        if (live) attempted++;
         if (accept_step) {
 #pragma unroll
             for (int b = 0; b < N; b++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) s.p[b][c] = p6[b][c], s.v[b][c] = v6[b][c];
             s.t += h;
-            accepted++;
+            if (live) accepted++;
         }
         // monitor runs only for lanes that accepted (L283); the call itself is wave-wide
         if (MON != MON_OFF && MON != MON_ON) {
-            mon_call<N, true>(ms, s, mp, lg, accept_step); // printing / every-step monitors: inline
+            mon_call<N, true>(ms, s, mp, lg, accept_step && live); // printing / every-step monitors: inline
         } else if (MON) {
-            bool maybe = accept_step;
+            const bool stepped = accept_step && live;
+            bool maybe = stepped;
             if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL) {
 #pragma clang fp contract(off)
-                maybe = accept_step && mp.log_interval != 0. && s.t >= ms.next_log_time;
+                maybe = stepped && mp.log_interval != 0. && s.t >= ms.next_log_time;
             } else { // stop_on_ejection (the composite with a close-encounter part runs as MON_VERBOSE)
                 maybe = false;
-                if (accept_step && mp.ej_any) {
+                if (stepped && mp.ej_any) {
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
@@ -206,12 +218,13 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
             if (__any(maybe)) {
                 State<N> tmp = s;
                 MonState mtmp = ms;
-                rkck_mon_call<N, false>(&mtmp, &tmp, &mp, &lg, accept_step);
+                rkck_mon_call<N, false>(&mtmp, &tmp, &mp, &lg, stepped);
                 s = tmp;
                 ms = mtmp;
             }
         }
-        if (accept_step && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
+        if (accept_step && live && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
+        live = live && s.state == SWARM_HIP_ACTIVE;
     }
     if (accepted || s.state != state_in) store_state(e, gid, s);
     if (cnt.accepted) cnt.accepted[gid] += accepted;

@@ -106,3 +106,138 @@ def gather_ensemble(shard, nsys_total, dist=None, device=None):
         full.state[lo:hi] = cut(1)[:, 0].astype(np.int32)
         full.id[lo:hi] = cut(1)[:, 0].astype(np.int32)
     return full
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sharded run (BASELINE configs[3]: mvs, nsys = 2^20, nbod = 8 over 8 GPUs).  Every rank owns the same number of
+# wave chunks (`capacity`; the last ranks may hold fewer real systems), integrates them with no exchange at all, and
+# then takes part in two collectives: one all_gather_into_tensor of the 8-double statistics vector of
+# swarm_hip_energy_stats, and one all_gather_into_tensor per device buffer (body, sysd, sysi) into preallocated
+# outputs.  Because a shard is a contiguous run of wave chunks, the gathered buffers ARE the wave-chunk image of the
+# whole ensemble: no unpacking step follows the collective.
+#
+# The device work goes through a `backend` with the five calls below.  HipShardBackend (the product) makes them C-ABI
+# calls on torch-owned device memory; tests/test_parallel_gloo.py supplies a CPU stand-in so that the same harness --
+# partition, collectives, verification -- runs under gloo without a GPU.
+
+class HipShardBackend:
+    """One rank's shard on its GPU: torch owns the bytes, libswarm_hip.so does the work."""
+
+    def __init__(self, capacity, nsys, nbod, device, nbattr=1, nsattr=1):
+        import torch
+        from . import capi
+        from .ensemble import DeviceEnsemble
+        L = capi.lib
+        self.capacity, self.nsys, self.nbod, self.nbattr, self.nsattr, self.device = capacity, nsys, nbod, nbattr, nsattr, device
+        sizes = (L.swarm_hip_body_bytes(capacity, nbod, nbattr), L.swarm_hip_sysd_bytes(capacity, nsattr),
+                 L.swarm_hip_sysi_bytes(capacity))
+        self.buffers = [torch.zeros(max(n, 8), dtype=torch.uint8, device=device) for n in sizes]
+        # lanes this rank does not own: DISABLED (-1), id -1 -- all-ones bytes in the int32 buffer
+        self.buffers[2].fill_(0xFF)
+        self.dens = DeviceEnsemble(nsys, nbod, nbattr, nsattr, pointers=[b.data_ptr() for b in self.buffers])
+        self._e0 = None
+
+    def upload(self, host):
+        if self.nsys:
+            self.dens.upload(host)
+            self._e0 = self._energy()
+
+    def _energy(self):
+        import torch
+        from . import capi
+        n = capi.lib.swarm_hip_nchunk(self.nsys) * CHUNK
+        t = torch.empty(max(n, 1), dtype=torch.float64, device=self.device)
+        capi.check(capi.lib.swarm_hip_total_energy(self.dens.ref, t.data_ptr(), None))
+        return t
+
+    def integrate(self, cfg, destination_time):
+        from .integrator import Integrator
+        if not self.nsys:
+            return
+        integ = Integrator.create(cfg)
+        integ.set_ensemble(None, self.dens)
+        integ.set_destination_time(destination_time)
+        integ.core_integrate()
+
+    def stats(self):
+        """device tensor of 8 doubles: {sum, max, min of |dE/E0|, n_active, n_inactive, n_disabled, n_other, nsys}"""
+        import torch
+        from . import capi
+        out = torch.zeros(8, dtype=torch.float64, device=self.device)
+        out[2] = float("inf")
+        if self.nsys:
+            e1 = self._energy()
+            capi.check(capi.lib.swarm_hip_energy_stats(self.dens.ref, self._e0.data_ptr(), e1.data_ptr(), out.data_ptr(), None))
+            capi.check(capi.lib.swarm_hip_synchronize(None))
+        return out
+
+    def download_image(self, buffers, nsys):
+        """host ensemble of the first nsys systems of a wave-chunk image held in three device tensors"""
+        from .ensemble import DeviceEnsemble
+        return DeviceEnsemble(nsys, self.nbod, self.nbattr, self.nsattr, pointers=[b.data_ptr() for b in buffers]).download()
+
+
+def combine_stats(rows):
+    """[world, 8] statistics vectors -> one dict (sum / max / min / counts)"""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 8)
+    out = {"sum_abs_dE_over_E": float(rows[:, 0].sum()), "max_abs_dE_over_E": float(rows[:, 1].max()),
+           "min_abs_dE_over_E": float(rows[:, 2].min())}
+    for k, name in enumerate(("n_active", "n_inactive", "n_disabled", "n_other", "nsys")):
+        out[name] = float(rows[:, 3 + k].sum())
+    out["mean_abs_dE_over_E"] = out["sum_abs_dE_over_E"] / max(out["nsys"], 1.0)
+    return out
+
+
+def run_sharded(nsys_total, make_shard, make_backend, cfg, destination_time, dist=None, rank=0, world=1,
+                sync=lambda: None, clock=None, verify=True):
+    """Partition, integrate, exchange, verify.  make_shard(lo, hi) -> host ensemble of systems [lo, hi) with ids
+    lo..hi-1; make_backend(capacity, nsys) -> backend.  Returns a dict with the combined statistics, the integrate
+    and gather times of this rank, and (rank 0, verify=True) the outcome of the checks on the gathered image."""
+    import time
+    import torch
+    clock = clock or time.perf_counter
+    bounds = shard_bounds(nsys_total, world)
+    lo, hi = bounds[rank]
+    capacity = max(h - l for l, h in bounds)
+    capacity = (capacity + CHUNK - 1) // CHUNK * CHUNK
+    be = make_backend(capacity, hi - lo)
+    shard = make_shard(lo, hi)
+    be.upload(shard)
+    multi = dist is not None and dist.is_initialized()
+    sync()
+    if multi:
+        dist.barrier()
+    t0 = clock()
+    be.integrate(cfg, destination_time)
+    sync()
+    t_integrate = clock() - t0
+    # statistics: one collective
+    mine = be.stats()
+    if multi:
+        allstats = torch.empty(world * 8, dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(allstats, mine)
+    else:
+        allstats = mine
+    stats = combine_stats(allstats.cpu().numpy())
+    # final shards: one collective per buffer into a preallocated image of world * capacity systems
+    sync()
+    t0 = clock()
+    if multi:
+        gathered = [torch.empty(world * b.numel(), dtype=b.dtype, device=b.device) for b in be.buffers]
+        for g, b in zip(gathered, be.buffers):
+            dist.all_gather_into_tensor(g, b)
+    else:
+        gathered = be.buffers
+    sync()
+    t_gather = clock() - t0
+    res = {"stats": stats, "integrate_s": t_integrate, "gather_s": t_gather, "bounds": bounds, "capacity": capacity,
+           "gathered_bytes": int(sum(g.numel() for g in gathered))}
+    if verify:
+        # every rank: its own bytes sit at its offset of the gathered image
+        own = all(torch.equal(g[rank * b.numel():(rank + 1) * b.numel()], b) for g, b in zip(gathered, be.buffers))
+        res["own_bytes_in_place"] = bool(own)
+        if rank == 0:
+            full = be.download_image(gathered, nsys_total)
+            res["ids_are_arange"] = bool((full.id == np.arange(nsys_total)).all())
+            res["full"] = full
+    return res

@@ -42,39 +42,95 @@ WORKLOADS = {
     "irk2": dict(integrator="irk2", nsys=65536, nbod=3, T=10.0, cfg={"time_step": "0.01"}),
     "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
                      cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
+    # C3 where it is divergent: geometrically scaled systems (size factor 0.03 .. 1, dynamical times spread over a
+    # factor ~190), a tolerance that rejects attempts, rmax that ejects the widest ~8 % at once; --shuffle puts the
+    # systems in random order (every wave mixes fast and slow systems), without it neighbours are alike
+    "c3_div": dict(integrator="rkck_adaptive", nsys=65536, nbod=6, T=2.0, ensemble="scaled",
+                   cfg={"min_time_step": "1e-5", "max_time_step": "0.02", "error_tolerance": "1e-24",
+                        "deactivate_on_ejection": "1", "rmax": "30"}),
 }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=sorted(WORKLOADS))
-    ap.add_argument("--nsys", type=int)
-    ap.add_argument("--nbod", type=int)
-    ap.add_argument("--T", type=float)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--lane-mode", type=int, default=0, help="0 auto, 1 lane per system, 2 lane per body (hermite)")
-    ap.add_argument("--spread", type=float, default=0.0, help="scale systems geometrically by up to this factor")
-    ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
-    a = ap.parse_args()
-    w = dict(WORKLOADS[a.workload])
-    nsys, nbod, T = a.nsys or w["nsys"], a.nbod or w["nbod"], a.T or w["T"]
+def hermite_flops(n, adaptive=False):   # 118 P + 159 n (+ 9 n + 4 for the adaptive step size)
+    return 118 * (n * (n - 1) // 2) + 159 * n + ((9 * n + 4) if adaptive else 0)
+
+
+def rkck_flops(n):                      # per ATTEMPTED step: 150 P + 390 n
+    return 150 * (n * (n - 1) // 2) + 390 * n
+
+
+# mean Laguerre passes per Kepler solve on the generated ensemble at dt = 0.01 (counted with the CPU restatement:
+# every solve makes 3 passes, 26 % a fourth, 10 % all seven)
+MVS_MEAN_PASSES = 3.56
+
+
+def mvs_flops(n, passes=MVS_MEAN_PASSES):   # 25 (n-1)(n-2)/2 + (n-1)(50 iters + 70) + 36 n
+    return 25 * ((n - 1) * (n - 2) // 2) + (n - 1) * (50 * passes + 70) + 36 * n
+
+
+def flops_per_step(integrator, nbod):
+    """algorithmic flops per accepted step -- per ATTEMPTED step for rkck; None where the survey has none"""
+    if integrator.startswith("hermite_adap"):
+        return hermite_flops(nbod, True)
+    if integrator.startswith("hermite"):
+        return hermite_flops(nbod)
+    if integrator.startswith("rkck"):
+        return rkck_flops(nbod)
+    if integrator.startswith("mvs"):
+        return mvs_flops(nbod)
+    return None
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def make_ensemble(w, nsys, nbod, spread=0.0, shuffle=False):
+    host = S.generate_ensemble(S.config({"nsys": str(nsys), "nbod": str(nbod)}))
+    if w.get("ensemble") == "scaled":      # tests/conftest.py `scaled`: perturbed, then sized 0.03 .. 1
+        rng = np.random.default_rng(3)
+        host.pos[:, 1:, :] *= 1.0 + 1e-2 * rng.standard_normal((nsys, nbod - 1, 3))
+        host.vel[:, 1:, :] *= 1.0 + 1e-2 * rng.standard_normal((nsys, nbod - 1, 3))
+        host.pos[:, 1:, 2] += 1e-2 * rng.standard_normal((nsys, nbod - 1))
+        s = np.geomspace(0.03, 1.0, nsys)
+        if shuffle:
+            rng.shuffle(s)
+        s = s[:, None, None]
+        host.pos *= s
+        host.vel /= np.sqrt(s)
+    if spread > 1:
+        s = np.geomspace(1.0 / spread, 1.0, nsys)[:, None, None]
+        host.pos *= s
+        host.vel /= np.sqrt(s)
+    return host
+
+
+def lane_utilisation(att):
+    """sum of lane-attempts / (64 x wave-attempts): a wave runs until its slowest lane is done"""
+    att = np.asarray(att, dtype=np.float64)
+    pad = (-len(att)) % 64
+    waves = np.concatenate([att, np.zeros(pad)]).reshape(-1, 64)
+    return float(att.sum() / max(64.0 * waves.max(axis=1).sum(), 1.0))
+
+
+def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0, spread=0.0, shuffle=False,
+            pinned=False, host_to_host=True, extra_cfg=None):
+    """kernel time of one launch (HIP events on the launch stream), best of `reps`; step counts; optional
+    host-to-host time of integrate()"""
+    w = dict(WORKLOADS[workload])
+    nsys, nbod, T = nsys or w["nsys"], nbod or w["nbod"], T or w["T"]
     S.capi.check(S.capi.lib.swarm_hip_init(0))
     L = S.capi.lib
-    host0 = S.generate_ensemble(S.config({"nsys": str(nsys), "nbod": str(nbod)}))
-    if a.spread > 1:
-        s = np.geomspace(1.0 / a.spread, 1.0, nsys)[:, None, None]
-        host0.pos *= s
-        host0.vel /= np.sqrt(s)
-    cfg = dict(w["cfg"], integrator=w["integrator"], lane_mode=str(a.lane_mode))
+    host0 = make_ensemble(w, nsys, nbod, spread, shuffle)
+    cfg = dict(w["cfg"], integrator=w["integrator"], lane_mode=str(lane_mode))
+    cfg.update(extra_cfg or {})
     res = []
-    for rep in range(a.reps):
+    for rep in range(reps):
         host = host0.clone()
         integ = S.Integrator.create(S.config(cfg))
         integ.set_ensemble(host)
         integ.set_destination_time(T)
-        if a.block:
-            integ.args.block_size = a.block
+        if block:
+            integ.args.block_size = block
         lm = None
         if w.get("log"):
             lm = S.LogManager(w["log"], "count")
@@ -91,36 +147,87 @@ def main():
         tk = time.perf_counter()
         integ.flush_log()
         tf = time.perf_counter()
-        attempts = 1
-        if integ._dens.count_active() != 0:
-            attempts += integ.core_integrate()
         ms = C.c_float()
         L.swarm_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+        acc1, att1 = integ.step_counts()         # of the timed launch alone
+        attempts = 1
+        # the launches that follow (rkck caps a launch at destination_time / max_time_step attempts,
+        # rkck_integrator.hpp:75): lane-attempts and wave-attempts of each, for the utilisation over the whole run
+        lane_att, wave_att, prev = float(att1.sum()), 64.0 * np.pad(att1.astype(np.float64), (0, (-len(att1)) % 64)).reshape(-1, 64).max(axis=1).sum(), att1
+        launch_ms = [ms.value]
+        while integ._dens.count_active() != 0 and attempts < integ._max_attempts:
+            L.swarm_hip_event_record(e0, None)
+            integ.launch_integrator()
+            L.swarm_hip_event_record(e1, None)
+            L.swarm_hip_synchronize(None)
+            integ.flush_log()
+            m2 = C.c_float()
+            L.swarm_hip_event_elapsed_ms(e0, e1, C.byref(m2))
+            launch_ms.append(m2.value)
+            attempts += 1
+            _, now = integ.step_counts()
+            d = (now - prev).astype(np.float64)
+            prev = now
+            lane_att += d.sum()
+            wave_att += 64.0 * np.pad(d, (0, (-len(d)) % 64)).reshape(-1, 64).max(axis=1).sum()
         wall = time.perf_counter() - t0
         acc, att = integ.step_counts()
         integ.download_ensemble()
-        res.append(dict(ms=ms.value, wall_ms=wall * 1e3, accepted=int(acc.sum()), attempted=int(att.sum()),
-                        attempts=attempts, flush_ms=(tf - tk) * 1e3, log_bytes=lm.bytes_flushed if lm else 0, dropped=lm.dropped if lm else 0,
+        L.swarm_hip_event_destroy(e0); L.swarm_hip_event_destroy(e1)
+        res.append(dict(ms=ms.value, wall_ms=wall * 1e3, accepted=int(acc1.sum()), attempted=int(att1.sum()),
+                        accepted_all_launches=int(acc.sum()), attempts=attempts, flush_ms=(tf - tk) * 1e3,
+                        log_bytes=lm.bytes_flushed if lm else 0, dropped=lm.dropped if lm else 0,
+                        lane_utilisation=lane_utilisation(att1), lane_utilisation_all_launches=lane_att / max(wave_att, 1.0),
+                        attempted_all_launches=int(att.sum()), kernel_ms_all_launches=sum(launch_ms),
+                        launch_ms=[round(x, 4) for x in launch_ms],
+                        accepted_min_max=[int(acc.min()), int(acc.max())],
                         states={int(k): int(v) for k, v in zip(*np.unique(host.state, return_counts=True))}))
-    # host-to-host time of integrator.integrate(): upload (pack + H2D), kernel(s), flush, D2H + unpack
-    e2e_ms = float("inf")
-    for _ in range(2):  # best of two: the host work above leaves the GPU idle long enough for its clock to drop
-        host = host0.clone(pinned=a.pinned)
-        integ = S.Integrator.create(S.config(cfg))
-        integ.set_ensemble(host)
-        integ.set_destination_time(T)
-        if w.get("log"):
-            integ.set_log_manager(S.LogManager(w["log"], "count"))
-        t0 = time.perf_counter()
-        integ.integrate()
-        e2e_ms = min(e2e_ms, (time.perf_counter() - t0) * 1e3)
     best = min(res, key=lambda r: r["ms"])
-    best["host_to_host_ms"] = e2e_ms
-    best["pinned_host"] = bool(a.pinned)
-    out = dict(workload=a.workload, integrator=w["integrator"], nsys=nsys, nbod=nbod, T=T, **best)
+    if host_to_host:
+        # host-to-host time of integrator.integrate(): upload (pack + H2D), kernel(s), flush, D2H + unpack
+        e2e_ms = float("inf")
+        for _ in range(2):  # best of two: the host work above leaves the GPU idle long enough for its clock to drop
+            host = host0.clone(pinned=pinned)
+            integ = S.Integrator.create(S.config(cfg))
+            integ.set_ensemble(host)
+            integ.set_destination_time(T)
+            if w.get("log"):
+                integ.set_log_manager(S.LogManager(w["log"], "count"))
+            t0 = time.perf_counter()
+            integ.integrate()
+            e2e_ms = min(e2e_ms, (time.perf_counter() - t0) * 1e3)
+        best["host_to_host_ms"] = e2e_ms
+        best["pinned_host"] = bool(pinned)
+    out = dict(workload=workload, integrator=w["integrator"], nsys=nsys, nbod=nbod, T=T, **best)
     out["accepted_steps_per_s"] = best["accepted"] / (best["ms"] * 1e-3)
     out["attempted_steps_per_s"] = best["attempted"] / (best["ms"] * 1e-3)
-    print(json.dumps(out))
+    f = flops_per_step(w["integrator"], nbod)
+    if f:
+        out["flop_per_step"] = f
+        out["algorithmic_tflops"] = f * best["attempted"] / (best["ms"] * 1e-3) / 1e12
+        out["frac_of_fp64_peak"] = out["algorithmic_tflops"] / FP64_VECTOR_PEAK_TFLOPS
+    return out
+
+
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=sorted(WORKLOADS))
+    ap.add_argument("--nsys", type=int)
+    ap.add_argument("--nbod", type=int)
+    ap.add_argument("--T", type=float)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--lane-mode", type=int, default=0, help="0 auto, 1 lane per system, 2 lane per body (hermite)")
+    ap.add_argument("--spread", type=float, default=0.0, help="scale systems geometrically by up to this factor")
+    ap.add_argument("--shuffle", action="store_true", help="c3_div: systems in random order")
+    ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
+    ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("cfg", nargs="*", help="extra key=value configuration pairs")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.workload, a.nsys, a.nbod, a.T, a.reps, a.block, a.lane_mode, a.spread, a.shuffle,
+                             a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg))))
 
 
 if __name__ == "__main__":
