@@ -11,6 +11,14 @@ without the H2D/D2H copies: inputs are resident in HBM).
 N > 1: one process per GPU (torchrun), the ensemble is partitioned by system index, each rank
 integrates its own shard (no data-path collective); after the timed region the energy/ejection
 statistics are all-reduced and the final shards gathered over RCCL, outside the timing.
+
+At N = 1 the JSON line also carries a "secondary" block: BASELINE's other single-GPU configurations (C3
+rkck_adaptive 65536 x 6 in its cruising and its divergent regime, one C4 shard of mvs 131072 x 8, C5
+hermite_adap_log 65536 x 4), one or two launches each, kernel time by HIP events (tools/perf.py measure()).
+
+--config c4 runs BASELINE configs[3] itself: mvs, time_step = 0.01, nsys = 2^20, nbod = 8 partitioned over the
+ranks (swarm_amd.parallel.run_sharded: shard_bounds, one launch loop per shard, all_gather_into_tensor of the
+statistics vector and of the three device buffers into preallocated outputs, verification on rank 0).
 """
 import argparse
 import ctypes as C
@@ -25,6 +33,41 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = {3: 831}  # F_hermite(n) = 118*P + 159*n
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz
+
+
+def profiled_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/rN/<tag>_pmc.json, newest round first): FETCH_SIZE (KB, doubled on gfx950 per the MI355X guide) +
+    WRITE_SIZE (KB).  None when no profile is committed."""
+    base = os.path.join(ROOT, "profiles")
+    for rnd in sorted((d for d in os.listdir(base) if d.startswith("r")), reverse=True) if os.path.isdir(base) else []:
+        fn = os.path.join(base, rnd, tag + "_pmc.json")
+        if os.path.exists(fn):
+            c = json.load(open(fn))
+            c = c.get("counters", c)
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return {"bytes": c["FETCH_SIZE"]["per_launch_avg"] * 1024 * 2 + c["WRITE_SIZE"]["per_launch_avg"] * 1024,
+                        "source": os.path.relpath(fn, ROOT)}
+    return None
+
+
+def secondary_block():
+    """BASELINE's other single-GPU configurations, one short measurement each (kernel time by HIP events)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import perf
+    out = {}
+    for tag, workload, kw in (("c3_rkck_adaptive_cruising", "c3", {}),
+                              ("c3_rkck_adaptive_divergent", "c3_div", {"shuffle": True}),
+                              ("c4_mvs_shard", "c4", {}),
+                              ("c5_hermite_adap_log", "c5", {})):
+        r = perf.measure(workload, reps=2, host_to_host=False, **kw)
+        keep = {k: r[k] for k in ("integrator", "nsys", "nbod", "T", "ms", "accepted", "attempted", "attempts",
+                                  "accepted_steps_per_s", "attempted_steps_per_s", "flop_per_step", "algorithmic_tflops",
+                                  "frac_of_fp64_peak", "lane_utilisation_all_launches", "kernel_ms_all_launches",
+                                  "log_bytes", "flush_ms") if k in r}
+        keep["ms_is"] = "first launch, HIP events on the launch stream"
+        out[tag] = keep
+    return out
 
 
 def hermite_flops(n):
@@ -43,6 +86,11 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=18.0)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2: the headline (Hermite.cfg, 65536 x 3 per GPU); c4: mvs 2^20 x 8 sharded over the ranks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary block (N = 1 only)")
+    ap.add_argument("--c4-nsys", type=int, default=1 << 20)
+    ap.add_argument("--c4-span", type=float, default=10.0, help="c4: destination_time (1000 steps of 0.01)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the post-run exchange runs "
                          "over gloo on host copies (RCCL refuses two ranks on one device)")
@@ -71,6 +119,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     S.capi.check(S.capi.lib.swarm_hip_init(local_rank))
     L = S.capi.lib
+    if args.config == "c4":
+        return bench_c4(args, S, torch, dist, dev, cdev, rank, world)
 
     nsys, nbod = args.nsys, args.nbod
     # global ensemble partitioned by system index: this rank owns [rank*nsys, (rank+1)*nsys)
@@ -148,23 +198,31 @@ def main():
     # energy / ejection statistics: one small all-reduce (sum, max, min) over RCCL
     stats = P.allreduce_stats(*P.local_stats(derr, final.state, steps_accepted=nsys * steps_per_pass * args.steps),
                               dist=dist, device=cdev)
-    gather_ms = None
+    gather_ms, gather_ok = None, None
     if dist is not None:
-        # final ensemble gather: the device shards are contiguous byte ranges, one all_gather each
+        # final ensemble gather: a shard is a contiguous run of wave chunks, so ONE all_gather_into_tensor per device
+        # buffer into a preallocated output gives the wave-chunk image of the whole ensemble
+        srcs = [t.to(cdev) for t in (tb, td, ti)]
+        outs = [torch.empty(world * t.numel(), dtype=t.dtype, device=cdev) for t in srcs]
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        for t in (tb, td, ti):
-            t = t.to(cdev)
-            shards = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(shards, t)
+        for o, t in zip(outs, srcs):
+            dist.all_gather_into_tensor(o, t)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        # every rank: its own bytes sit at its offset; rank 0: the gathered ids are 0 .. world * nsys - 1
+        gather_ok = all(torch.equal(o[rank * t.numel():(rank + 1) * t.numel()], t) for o, t in zip(outs, srcs))
+        if rank == 0:
+            ids = outs[2].view(torch.int32).reshape(-1, 2, 64)[:, 1, :].reshape(-1).cpu().numpy()
+            gather_ok = gather_ok and bool((ids == np.arange(world * nsys)).all())
+        assert gather_ok, "gathered shards differ from the local ones"
 
     total_sys_steps = float(world) * nsys * steps_per_pass * args.steps
     value = total_sys_steps / elapsed
     flops = hermite_flops(nbod)
     achieved = flops * nsys * steps_per_pass / (kernel_ms_avg * 1e-3) / 1e12 if kernel_ms_avg > 0 else 0.0
 
+    traffic = profiled_traffic("hermite_n3") if (nbod, nsys) == (3, 65536) else None
     out = {
         "metric": "system-steps/sec, Hermite nbod=3 nsys=64k" if (nbod, nsys) == (3, 65536)
         else "system-steps/sec, Hermite nbod=%d nsys=%d" % (nbod, nsys),
@@ -188,7 +246,8 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                      # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE doubled per
                      # the MI355X guide + WRITE_SIZE), profiles/r1/hermite_n3_pmc.json; algorithmic = 340 B/system
-                     "traffic": 22216997 if (nbod, nsys) == (3, 65536) else None,
+                     "traffic": traffic["bytes"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None,
                      "kernel": "hermite_kernel<%d,false,0>" % nbod,
                      "kernel_ms_avg": kernel_ms_avg,
                      "flop_per_system_step": flops,
@@ -199,6 +258,9 @@ def main():
     }
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
+        out["gather_verified"] = bool(gather_ok)
+    if rank == 0 and world == 1 and dist is None and not args.no_secondary:
+        out["secondary"] = secondary_block()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -223,6 +285,69 @@ def main():
                                          % (cn, nbod, args.time_step, int(acc[0]), ct)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_c4(args, S, torch, dist, dev, cdev, rank, world):
+    """BASELINE configs[3]: mvs, nsys = 2^20, nbod = 8, time_step = 0.01, partitioned over the ranks.  One bench step
+    = the whole run (destination_time = --c4-span); `value` = system-steps of all ranks / the slowest rank's time."""
+    import numpy as np
+    from swarm_amd import parallel as P
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import perf
+    nsys_total, nbod = args.c4_nsys, 8
+    cfg = S.config({"integrator": "mvs", "time_step": "0.01"})
+
+    def make_shard(lo, hi):
+        h = S.generate_ensemble(S.config({"nsys": str(max(hi - lo, 1)), "nbod": str(nbod)}))
+        if hi - lo == 0:
+            h = h.slice(0, 0)
+        h.id[:] = np.arange(lo, hi)
+        return h
+    if args.rehearse_one_gpu:
+        raise SystemExit("--config c4 exchanges device buffers over RCCL: one rank per GPU")
+    times = []
+    res = None
+    for k in range(args.warmup + args.steps):
+        res = P.run_sharded(nsys_total, make_shard, lambda cap, n: P.HipShardBackend(cap, n, nbod, dev), cfg,
+                            args.c4_span, dist=dist, rank=rank, world=world, sync=torch.cuda.synchronize,
+                            verify=(k == args.warmup + args.steps - 1))
+        t = torch.tensor([res["integrate_s"], res["gather_s"]], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if k >= args.warmup:
+            times.append(t.cpu().numpy())
+    integ_s = float(np.mean([t[0] for t in times]))
+    gather_s = float(np.mean([t[1] for t in times]))
+    steps_per_system = int(round(args.c4_span / 0.01)) + 1      # the 1001st step closes the rounding gap to T
+    total = float(nsys_total) * steps_per_system
+    flops = perf.mvs_flops(nbod)
+    achieved = flops * total / world / integ_s / 1e12
+    ok = bool(res["own_bytes_in_place"]) and (rank != 0 or bool(res["ids_are_arange"]))
+    assert ok, "gathered image differs from the shards"
+    if rank == 0:
+        full = res["full"]
+        assert (full.state == 1).all() and np.allclose(full.time, args.c4_span, rtol=1e-12)
+        print(json.dumps({
+            "metric": "system-steps/sec, MVS nbod=8 nsys=%d over %d GPU(s)" % (nsys_total, world),
+            "value": total / integ_s, "unit": "system-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": integ_s * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "MVS.cfg time_step=0.01, nsys=%d nbod=8, generate_ensemble systems, destination_time=%g "
+                                   "(%d steps per system), shards of %d systems" % (nsys_total, args.c4_span, steps_per_system,
+                                                                                    res["capacity"]),
+                       "integrator": "mvs", "partition": "by system index, %d shard(s), no data-path collective" % world},
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "generic_kernel<8,MVS,0>", "flop_per_system_step": flops,
+                         "note": "per GPU; the time is host to host over the shard's launch loop"},
+            "exchange": {"gather_ms": gather_s * 1e3, "gathered_bytes": res["gathered_bytes"],
+                         "collectives": "all_gather_into_tensor x 4 (statistics, body, sysd, sysi)",
+                         "own_bytes_in_place": True, "ids_are_arange": True},
+            "energy": {"max_rel_err": res["stats"]["max_abs_dE_over_E"], "mean_rel_err": res["stats"]["mean_abs_dE_over_E"],
+                       "n_inactive": int(res["stats"]["n_inactive"]), "n_systems": int(res["stats"]["nsys"])},
+        }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
