@@ -54,6 +54,41 @@ def test_upload_download_roundtrip(gpu, oracle, nsys, nbod):
     np.testing.assert_array_equal(en, O.total_energy(e))      # same operation order, no FMA: bit-exact
 
 
+@pytest.mark.parametrize("nbod,nbattr,nsattr", [(3, 1, 1), (5, 3, 1), (4, 4, 2), (8, 3, 2), (10, 13, 1)])
+def test_upload_download_roundtrip_with_attributes(gpu, nbod, nbattr, nsattr):
+    """AoS <-> wave chunks with several body and system attributes (the LDS-tiled kernel's body-attribute group has
+    F = nbod * nbattr columns), a ragged last chunk, and NULL attribute arrays on upload (zero-filled on the device).
+    nbod = 10 with 13 attributes needs a 67 KB tile, more than the tiled kernel takes: that case goes through the
+    lane-per-system conversion kernel."""
+    S = gpu
+    nsys = 64 * 3 + 17
+    rng = np.random.default_rng(nbod * 100 + nbattr)
+    h = S.HostEnsemble(nsys, nbod, nbattr, nsattr)
+    for k in ("pos", "vel", "mass", "time", "body_attr", "sys_attr"):
+        getattr(h, k)[...] = rng.standard_normal(getattr(h, k).shape)
+    h.state[:] = rng.integers(-1, 3, nsys)
+    h.id[:] = rng.permutation(nsys)
+    d = S.DeviceEnsemble(nsys, nbod, nbattr, nsattr)
+    d.upload(h)
+    back = d.download()
+    for k in ("pos", "vel", "mass", "time", "state", "id", "body_attr", "sys_attr"):
+        assert (getattr(back, k) == getattr(h, k)).all(), k
+    # the device image itself: row (b, 7 + a) of chunk k holds attribute a of body b for the chunk's 64 systems
+    img = S.DeviceBuffer.to_host(d._own[0], np.float64).reshape(-1, nbod, 7 + nbattr, 64)
+    k, l = np.arange(nsys) // 64, np.arange(nsys) % 64
+    for a in range(nbattr):
+        assert (img[k, nbod - 1, 7 + a, l] == h.body_attr[:, nbod - 1, a]).all()
+    assert (img[-1, :, :, 17:] == 0).all()                       # padding lanes of the ragged chunk
+    # NULL attribute arrays: zeros on the device, everything else as given
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    S.capi.check(S.capi.lib.swarm_hip_upload_aos(d.ref, ptr(h.pos), ptr(h.vel), ptr(h.mass), ptr(h.time), ptr(h.state),
+                                                 ptr(h.id), None, None))
+    back = d.download()
+    assert (back.body_attr == 0).all() and (back.sys_attr == 0).all()
+    for k in ("pos", "vel", "mass", "time", "state", "id"):
+        assert (getattr(back, k) == getattr(h, k)).all(), k
+
+
 def test_pinned_host_ensemble_and_kept_staging_buffer(gpu, oracle):
     """hostEnsemble (page-locked, types/allocators.hpp:93-110): same bytes through upload / integrate / download as
     the pageable defaultEnsemble; its arrays outlive the ensemble object.  The calls go large -> small -> large so
