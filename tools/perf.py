@@ -113,7 +113,7 @@ def lane_utilisation(att):
 
 
 def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0, spread=0.0, shuffle=False,
-            pinned=False, host_to_host=True, extra_cfg=None):
+            pinned=False, host_to_host=True, extra_cfg=None, warm=False):
     """kernel time of one launch (HIP events on the launch stream), best of `reps`; step counts; optional
     host-to-host time of integrate()"""
     w = dict(WORKLOADS[workload])
@@ -139,6 +139,29 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
         integ.upload_ensemble()
         e0 = C.c_void_p(); e1 = C.c_void_p()
         L.swarm_hip_event_create(C.byref(e0)); L.swarm_hip_event_create(C.byref(e1))
+        if warm:
+            # the same launch on a copy of the ensemble, enqueued directly ahead of the timed one: a launch that
+            # follows an idle gap runs its first milliseconds at a lower clock (C4 shard: 10.65 ms alone, 9.71 ms
+            # back to back, tools/exp_b2b.py), and the secondary configurations are 0.6 .. 11 ms long
+            wh = host0.clone()
+            wi = S.Integrator.create(S.config(cfg))
+            wi.set_ensemble(wh)
+            wi.set_destination_time(T)
+            if block:
+                wi.args.block_size = block
+            if w.get("log"):
+                wi.set_log_manager(lm)      # same buffer: flushed (and its cursor cleared) before the timed launch's flush
+            wi.upload_ensemble()
+            wi.launch_integrator()
+            if not lm:                      # and once more over the next span of time: the ramp outlasts a 10 ms launch
+                wi.set_destination_time(2 * T)
+                wi._dens.reactivate(None)
+                wi.launch_integrator()
+            if lm:
+                L.swarm_hip_synchronize(None)
+                lm.flush()
+                lm.bytes_flushed = 0
+                wi.launch_integrator()      # (already finished systems: returns at once; keeps the queue non-empty)
         L.swarm_hip_event_record(e0, None)
         t0 = time.perf_counter()
         integ.launch_integrator()
@@ -224,10 +247,11 @@ def main():
     ap.add_argument("--shuffle", action="store_true", help="c3_div: systems in random order")
     ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--warm", action="store_true", help="enqueue the same launch on a copy directly ahead of the timed one")
     ap.add_argument("cfg", nargs="*", help="extra key=value configuration pairs")
     a = ap.parse_args()
     print(json.dumps(measure(a.workload, a.nsys, a.nbod, a.T, a.reps, a.block, a.lane_mode, a.spread, a.shuffle,
-                             a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg))))
+                             a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg), a.warm)))
 
 
 if __name__ == "__main__":
