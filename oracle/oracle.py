@@ -57,7 +57,8 @@ class _Par(C.Structure):
                 ("destination_time", C.c_double), ("time_step", C.c_double),
                 ("time_step_factor", C.c_double), ("min_time_step", C.c_double),
                 ("max_time_step", C.c_double), ("error_tolerance", C.c_double),
-                ("max_timestep", C.c_double), ("timestep_scale", C.c_double), ("irk2_method", C.c_int32)]
+                ("max_timestep", C.c_double), ("timestep_scale", C.c_double), ("irk2_method", C.c_int32),
+                ("kepler_compensated", C.c_int32)]
 
 
 class _Cnt(C.Structure):
@@ -137,9 +138,10 @@ def monitor(kind=MON_EJECTION, rmax=FLT_MAX, deactivate_on_ejection=0, log_on_ej
 
 def params(integrator, destination_time, max_iterations=10000000, time_step=0.0, time_step_factor=0.0,
            min_time_step=0.0, max_time_step=0.0, error_tolerance=0.0, max_timestep=0.0,
-           timestep_scale=0.0, method=0):
+           timestep_scale=0.0, method=0, kepler_compensated=0):
     return _Par(INTEGRATORS[integrator], max_iterations, destination_time, time_step, time_step_factor,
-                min_time_step, max_time_step, error_tolerance, max_timestep, timestep_scale, method)
+                min_time_step, max_time_step, error_tolerance, max_timestep, timestep_scale, method,
+                int(kepler_compensated))
 
 
 class Log:

@@ -1015,7 +1015,7 @@ static double solvex(double r0dotv0, double alpha, double sqrtM1, double r0, dou
     return x;
 }
 
-static void drift_kepler(double *pp, double *vv, const double sqrtGM, const double deltaTime) {
+static void drift_kepler(double *pp, double *vv, const double sqrtGM, const double deltaTime, const int compensated) {
     double x_old = pp[0], y_old = pp[1], z_old = pp[2], vx_old = vv[0], vy_old = vv[1], vz_old = vv[2];
     double x = x_old, y = y_old, z = z_old, vx = vx_old, vy = vy_old, vz = vz_old;
     double r0 = sqrt(x * x + y * y + z * z);
@@ -1048,6 +1048,16 @@ static void drift_kepler(double *pp, double *vv, const double sqrtGM, const doub
     vx = dfdt * x_old + dgdt * vx_old;
     vy = dfdt * y_old + dgdt * vy_old;
     vz = dfdt * z_old + dgdt * vz_old;
+    if (compensated) { /* not the reference: the same expressions from fh = f - 1, gh = dg/dt - 1 */
+        const double fh = -(x2 / r0) * Cp, gh = -(x2 / r) * Cp;
+        if (fabs(g_p) > 1e-8) dfdt = (fh + gh + fh * gh) / g_p;
+        x = x_old + (fh * x_old + g_p * vx_old);
+        y = y_old + (fh * y_old + g_p * vy_old);
+        z = z_old + (fh * z_old + g_p * vz_old);
+        vx = vx_old + (dfdt * x_old + gh * vx_old);
+        vy = vy_old + (dfdt * y_old + gh * vy_old);
+        vz = vz_old + (dfdt * z_old + gh * vz_old);
+    }
     pp[0] = x, pp[1] = y, pp[2] = z;
     vv[0] = vx, vv[1] = vy, vv[2] = vz;
 }
@@ -1167,7 +1177,7 @@ static void generic_system(sysref s, const orc_params *P, const orc_monitor *M, 
             mvs_drift(&s, hby2);
             for (int b = 1; b < nbod; b++)
                 for (int c = 0; c < 3; c++) s.vel[b][c] += hby2 * acc_bc[b][c];
-            for (int b = 1; b < nbod; b++) drift_kepler(s.pos[b], s.vel[b], sqrtGM, 2.0 * hby2);
+            for (int b = 1; b < nbod; b++) drift_kepler(s.pos[b], s.vel[b], sqrtGM, 2.0 * hby2, P->kepler_compensated);
             gpu_acc_pairs(&s, sa);
             gpu_acc_sum(&s, sa, acc_bc, 1);
             for (int b = 1; b < nbod; b++)

@@ -95,6 +95,10 @@ typedef struct {
     double max_timestep;      /* verlet: max_timestep */
     double timestep_scale;    /* verlet */
     int32_t irk2_method;      /* irk2: method= (number of stages 2, 4 or 6; 0 = default 6) */
+    int32_t kepler_compensated; /* mvs: 0 = the f, g update exactly as propagators/keplerian.hpp:214-231 writes it;
+                                   1 = the same expressions from f-1 and dg/dt-1 (no reference counterpart: the
+                                   restatement of the product's kepler_compensated=1, used to show that everything
+                                   else in the MVS restatement agrees with the hermite_cpu goldens to 1e-13) */
 } orc_params;
 
 /* per-system counters, optional (may be NULL) */

@@ -205,3 +205,7 @@ def test_mvs_ctest_configuration_and_the_fg_rounding_floor(gpu, oracle, nbod):
     assert 0.5 * fp < pd < 1.05 * fp and 0.5 * fv < vd < 1.05 * fv, (pd, vd)
     pd, vd = dist(hc, ref)
     assert pd < 1e-11 and vd < 1e-11, (pd, vd)
+    oc = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
+    O.integrate(oc, O.params("mvs", 1.0, time_step=0.0003, kepler_compensated=1))
+    pd, vd = dist(hc, oc)                                      # the compensated kernel against its own restatement
+    assert pd < 1e-12 and vd < 1e-13, (pd, vd)
