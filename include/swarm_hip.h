@@ -125,8 +125,8 @@ typedef struct swarm_hip_launch {
     int32_t log_transits;                  /* log_transits= (log_transit, default 1)     */
     int32_t log_occultations;              /* log_occultations= (default 0)              */
     int32_t lane_mode;                     /* 0 = choose by nsys; 1 = one lane per system; 2 = one lane
-                                              per body (small ensembles; hermite and hermite_adap with a
-                                              no-op monitor or stop_on_ejection's deactivation alone,
+                                              per body (small ensembles; hermite, hermite_adap and mvs with
+                                              a no-op monitor or stop_on_ejection's deactivation alone,
                                               ignored elsewhere).  No reference key. */
     double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
                                               monitor's dt is time_step=                 */

@@ -11,82 +11,15 @@
 //  * systems that are not ACTIVE at launch are left untouched (the reference runs MVS
 //    init()/shutdown() coordinate round trips on them, which perturbs their last bits).
 #include "launch.hpp"
+#include "mvs_common.hpp"
 
 namespace swh {
 
-// sin and cos on [0, pi/4] by the fdlibm kernel polynomials (k_sin.c / k_cos.c, < 1 ulp / ~1 ulp): the
-// argument of the Stumpff functions is the eccentric-anomaly increment of one step, so it is almost always
-// in that range, and the library sincos() with its full range reduction costs three times as much.
-__device__ __forceinline__ void sincos_quarter(const double x, double &sn, double &cs) {
-    const double z = x * x;
-    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
-                      -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                      8.33333333332248946124e-03);
-    sn = __builtin_fma(x * z, __builtin_fma(z, rs, -1.66666666666666324348e-01), x);
-    const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
-                      -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                      2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-    cs = 1.0 - __builtin_fma(0.5, z, -(z * rc));
-}
-
-// ---- universal-variable Kepler drift: propagators/keplerian.hpp ------------------------------
-// SC_prussing, keplerian.hpp:61-87, including `float absy` and the float sqrt it selects.
-__device__ __forceinline__ void SC_prussing(double y, double &S, double &C) {
-    if (fabs(y) < 1e-4) {
-        S = (1.0 / 6.0) * (1.0 - y * (1.0 / 20.0) * (1.0 - y * (1.0 / 42.0) * (1.0 - y * (1.0 / 72.0))));
-        C = (1.0 / 2.0) * (1.0 - y * (1.0 / 12.0) * (1.0 - y * (1.0 / 30.0) * (1.0 - y * (1.0 / 56.0))));
-    } else {
-        float absy = (float)fabs(y);
-        double u = (double)sqrtf(absy);
-        double u3 = u * u * u;
-        if (y > 0.0) {
-            double sn, cs;
-            if (u <= 0.78539816339744830962)
-                sincos_quarter(u, sn, cs);
-            else
-                sincos(u, &sn, &cs);
-            S = fdiv(u - sn, u3);
-            C = fdiv(1.0 - cs, y);
-        } else {
-            S = fdiv(sinh(u) - u, u3);
-            C = fdiv(cosh(u) - 1.0, -y);
-        }
-    }
-}
-
-// Kepler drift of G planets in lockstep: per planet the iteration of solvex and the f, g update of drift_kepler
-// (keplerian.hpp:120-159, 175-236), with the Laguerre iterations of the G planets advancing together so that their G
-// independent dependency chains interleave (one lane owns the whole system, so without this every iteration is one
-// long serial chain of FP64 latencies).  A planet whose own loop condition `(i < 7) && !((i > 2) && (x + u == x))` has
-// failed keeps its x (select, no branch).  The Stumpff functions take the series branch of SC_prussing for all planets
-// with one wave-uniform test when every lane is in that regime (|alpha x^2| < 1e-4, the usual case for dt << orbital
-// period), and the general per-planet routine otherwise.
-//
-// The expressions are the reference's, regrouped so that one pass is ~45 issue slots instead of ~70 (the solver is
-// three quarters of an MVS step):
-//   S, C series       Horner in y with the expanded coefficients 1/3!, -1/5!, 1/7!, -1/9! and 1/2!, -1/4!, 1/6!, -1/8!
-//                     (keplerian.hpp:65-66 nests the same polynomial as products of (1 - y/k (...)))
-//   F                 x (sig0 xC + foo x^2 S + r0) - smu dt            (L146: sig0 x^2 C + foo x^3 S + r0 x - smu dt)
-//   dF                (sig0 x)(1 - yS) + foo x (xC) + r0               (L147)
-//   ddF               sig0 (1 - yC) + foo (x (1 - yS))                 (L148)
-//   z                 |16 dF^2 - 20 F ddF|                             (L149 with n = 5 written out)
-//   r0, 1/r0          one rsqrt of |p|^2 gives both
-// each value within an ulp or two of the reference's association; what the tests hold is 1e-10 against the CPU
-// restatement (and 4e-12 at MVS.cfg's step, tests/test_gpu_integrators.py).
-__device__ __forceinline__ void SC_series(const double y, double &S, double &C) {
-    S = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, -1.0 / 362880.0, 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
-    C = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
-}
-// The general routine, out of line and marked cold.  Inlined (14 copies of sincos/sinh/cosh at nbod 8) its register
-// needs put ~55 spill stores and reloads per step on the hot path of a kernel that never takes it -- 7.2 GB of scratch
-// traffic per C4-shard launch; measured on that shard (series regime): inline 14.3 ms, inline behind a branch-weight
-// hint 12.2 ms, this 10.8 ms, no general path at all 10.3 ms; in the trigonometric regime (systems shrunk 30x) 37.7 ms
-// inline against 19.1 ms.
-static __device__ __attribute__((noinline, cold)) void SC_prussing_outlined(double y, double *sc) {
-    double S, C;
-    SC_prussing(y, S, C);
-    sc[0] = S, sc[1] = C;
-}
+// Kepler drift of G planets in lockstep (the per-planet pieces are in mvs_common.hpp), with the Laguerre iterations of
+// the G planets advancing together so that their G independent dependency chains interleave (one lane owns the whole
+// system, so without this every iteration is one long serial chain of FP64 latencies).  The Stumpff functions take the
+// series branch of SC_prussing for all planets with one wave-uniform test when every lane is in that regime
+// (|alpha x^2| < 1e-4, the usual case for dt << orbital period), and the general per-planet routine otherwise.
 template <int G>
 __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], double (&C)[G]) {
     bool small = true;
@@ -107,125 +40,42 @@ __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], d
     }
 }
 
-// what the solver needs of the star and of the step; formed when the step size changes (once per launch, and again
-// for a clipped last step)
-struct KeplerConsts {
-    double smu, inv_smu, inv_GM; // sqrt(GM) of the star, its reciprocal, 1/GM
-    double dt, smudt, gmdt2;     // the drift's time span, smu dt, GM dt^2 (the numerator of solvex's initial guess)
-    __device__ __forceinline__ void set_star(const double sqrtGM) {
-        smu = sqrtGM;
-        inv_smu = rcp_full(sqrtGM);
-        inv_GM = rcp_full(sqrtGM * sqrtGM);
-        dt = -1.0;
-    }
-    __device__ __forceinline__ void set_dt(const double deltaTime) {
-        dt = deltaTime;
-        smudt = smu * deltaTime;
-        gmdt2 = smu * smu * deltaTime * deltaTime;
-    }
-};
-
 template <int N, int B0, int G>
 __device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerConsts &k, const bool compensated) {
-    double r0[G], inv_r0[G], alpha[G], sig0[G], foo[G], x[G], u[G];
-    bool live[G];
+    KeplerOrbit o[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const double(&p)[3] = s.p[B0 + g];
-        const double(&v)[3] = s.v[B0 + g];
-        const double rr = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-        inv_r0[g] = rsqrt_full(rr);
-        r0[g] = rr * inv_r0[g];
-        const double v2 = (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        const double r0dotv0 = (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]);
-        alpha[g] = (2.0 * inv_r0[g] - v2 * k.inv_GM);
-        foo[g] = 1.0 - r0[g] * alpha[g];
-        sig0[g] = r0dotv0 * k.inv_smu;
-        x[g] = k.gmdt2 * inv_r0[g];
-        u[g] = 1.0;
-        live[g] = true;
+    for (int g = 0; g < G; g++) kepler_begin(o[g], s.p[B0 + g], s.v[B0 + g], k);
+    // keplerian.hpp:143: the first three passes are unconditional ...
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double y[G], Sp[G], Cp[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) y[g] = kepler_y(o[g]);
+        SC_group<G>(y, Sp, Cp);
+#pragma unroll
+        for (int g = 0; g < G; g++) kepler_pass(o[g], k, y[g], Sp[g], Cp[g]);
     }
-    for (int i = 0; i < 7; i++) {
+    // ... and up to four more follow, until x has stopped moving for every planet of the wavefront
+    // (unrolled: a rolled tail costs 2 %, the whole loop rolled 17 %, C4 shard)
+#pragma unroll
+    for (int i = 3; i < 7; i++) {
         bool any = false;
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            live[g] = live[g] && !((i > 2) && (x[g] + u[g] == x[g]));
-            any = any || live[g];
-        }
+        for (int g = 0; g < G; g++) any = kepler_more(o[g], i) || any;
         if (!__any(any)) break;
         double y[G], Sp[G], Cp[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) y[g] = alpha[g] * (x[g] * x[g]);
+        for (int g = 0; g < G; g++) y[g] = kepler_y(o[g]);
         SC_group<G>(y, Sp, Cp);
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const double xx = x[g], x2 = xx * xx;
-            const double a = __builtin_fma(-y[g], Sp[g], 1.0), b = __builtin_fma(-y[g], Cp[g], 1.0);
-            const double xC = xx * Cp[g], x2S = x2 * Sp[g];
-            const double F = __builtin_fma(xx, __builtin_fma(sig0[g], xC, __builtin_fma(foo[g], x2S, r0[g])), -k.smudt);
-            const double dF = __builtin_fma(sig0[g] * xx, a, __builtin_fma(foo[g], xx * xC, r0[g]));
-            const double ddF = __builtin_fma(sig0[g], b, foo[g] * (xx * a));
-            const double az = fabs(__builtin_fma(16.0 * dF, dF, -20.0 * (F * ddF)));
-            const double z = az * rsqrt_full(fmax(az, 1e-300)); // sqrt; 0 for az = 0
-            double denom = dF < 0 ? dF - z : dF + z;
-            if (denom == 0.0) denom = 1e-8;
-            const double un = (5.0 * F) * rcp_full(denom);
-            u[g] = live[g] ? un : u[g];
-            x[g] = live[g] ? xx - un : xx;
-        }
+        for (int g = 0; g < G; g++) kepler_pass(o[g], k, y[g], Sp[g], Cp[g]);
     }
     double y[G], Sp[G], Cp[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) y[g] = alpha[g] * (x[g] * x[g]);
+    for (int g = 0; g < G; g++) y[g] = kepler_y(o[g]);
     SC_group<G>(y, Sp, Cp);
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        double(&p)[3] = s.p[B0 + g];
-        double(&v)[3] = s.v[B0 + g];
-        const double x_old = p[0], y_old = p[1], z_old = p[2], vx_old = v[0], vy_old = v[1], vz_old = v[2];
-        const double x_p = x[g], x2 = x_p * x_p;
-        const double a = __builtin_fma(-y[g], Sp[g], 1.0);
-        const double x2C = x2 * Cp[g];
-        double r = __builtin_fma(sig0[g] * x_p, a, __builtin_fma(foo[g], x2C, r0[g]));
-        if (r < 0.) r = 0.;
-        const double g_p = __builtin_fma(-(x2 * x_p) * k.inv_smu, Sp[g], k.dt);
-        // fh = f - 1 and gh = dg/dt - 1 (keplerian.hpp:214, 218)
-        const double fh = -(x2C * inv_r0[g]);
-        const double gh = -(x2C * rcp_full(r));
-        double f_p, dgdt, num;
-        if (!compensated) { // keplerian.hpp:214-231 as written: f and dg/dt rounded to doubles next to 1
-            f_p = 1.0 + fh;
-            dgdt = 1.0 + gh;
-            num = __builtin_fma(f_p, dgdt, -1.0);
-        } else {
-            // The same expressions in terms of fh and gh: f*dgdt - 1 = fh + gh + fh*gh.  Written with f and dgdt, both
-            // within ~GM dt^2/r^3 of 1, the difference f*dgdt - 1 keeps only the digits of fh and gh above the spacing
-            // of the doubles at 1 (1.1e-16), an error of ~1e-16/dt in dfdt that repeats with the same sign step after
-            // step (MVS.cfg, dt = 3e-4: 6e-9 ... 9e-8 in velocity at T = 1 for nbod 3..8, tools/mvs_parity.py).
-            // swarm_hip_launch_t::kepler_compensated, not a reference key.
-            num = fh + gh + fh * gh;
-        }
-        double dfdt = num * rcp_full(g_p);
-        if (__builtin_expect(__any(!(fabs(g_p) > 1e-8)), 0)) { // L222-224, a step too short for the quotient
-            const double alt = fdiv(x_p * k.smu, r * r0[g]) * (y[g] * Sp[g] - 1.0);
-            dfdt = fabs(g_p) > 1e-8 ? dfdt : alt;
-        }
-        if (!compensated) {
-            p[0] = f_p * x_old + g_p * vx_old;
-            p[1] = f_p * y_old + g_p * vy_old;
-            p[2] = f_p * z_old + g_p * vz_old;
-            v[0] = dfdt * x_old + dgdt * vx_old;
-            v[1] = dfdt * y_old + dgdt * vy_old;
-            v[2] = dfdt * z_old + dgdt * vz_old;
-        } else {
-            p[0] = x_old + (fh * x_old + g_p * vx_old);
-            p[1] = y_old + (fh * y_old + g_p * vy_old);
-            p[2] = z_old + (fh * z_old + g_p * vz_old);
-            v[0] = vx_old + (dfdt * x_old + gh * vx_old);
-            v[1] = vy_old + (dfdt * y_old + gh * vy_old);
-            v[2] = vz_old + (dfdt * z_old + gh * vz_old);
-        }
-    }
+    for (int g = 0; g < G; g++) kepler_end(o[g], k, y[g], Sp[g], Cp[g], compensated, true, s.p[B0 + g], s.v[B0 + g]);
 }
 
 // all planets 1..N-1, in groups of at most KEPLER_GROUP (register budget: 6 doubles per planet)
@@ -253,8 +103,8 @@ __device__ __forceinline__ void mvs_to_internal(State<N> &s) {
         for (int j = 0; j < N; ++j) {
             const double mj = s.m[j];
             mtot += mj;
-            sump += mj * s.p[j][c];
-            sumv += mj * s.v[j][c];
+            sump = __builtin_fma(mj, s.p[j][c], sump);
+            sumv = __builtin_fma(mj, s.v[j][c], sumv);
         }
         sumv /= mtot;
         s.v[0][c] = sumv;
@@ -277,8 +127,8 @@ __device__ __forceinline__ void mvs_to_std(State<N> &s) {
         for (int j = 1; j < N; ++j) {
             const double mj = s.m[j];
             mtot += mj;
-            sump += mj * s.p[j][c];
-            sumv += mj * s.v[j][c];
+            sump = __builtin_fma(mj, s.p[j][c], sump);
+            sumv = __builtin_fma(mj, s.v[j][c], sumv);
         }
         sump /= mtot;
         s.p[0][c] -= sump;
@@ -295,14 +145,16 @@ __device__ __forceinline__ void mvs_to_std(State<N> &s) {
 // divides per step less)
 template <int N>
 __device__ __forceinline__ void mvs_drift(State<N> &s, double hby2, double inv_m0) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         double mv = 0;
 #pragma unroll
-        for (int j = 1; j < N; ++j) mv += s.m[j] * s.v[j][c];
-        s.p[0][c] += hby2 * s.v[0][c];
+        for (int j = 1; j < N; ++j) mv = __builtin_fma(s.m[j], s.v[j][c], mv);
+        s.p[0][c] = __builtin_fma(hby2, s.v[0][c], s.p[0][c]);
+        const double shift = (mv * hby2) * inv_m0; // one product for all planets, then plain additions
 #pragma unroll
-        for (int b = 1; b < N; b++) s.p[b][c] += mv * hby2 * inv_m0;
+        for (int b = 1; b < N; b++) s.p[b][c] = s.p[b][c] + shift;
     }
 }
 
@@ -409,14 +261,14 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
 #pragma unroll
                 for (int b = 1; b < N; b++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
+                    for (int c = 0; c < 3; c++) s.v[b][c] = __builtin_fma(hby2, acc[b][c], s.v[b][c]);
                 if (2.0 * hby2 != kc.dt) kc.set_dt(2.0 * hby2);
                 drift_kepler_all<N>(s, kc, ip.kepler_compensated != 0);
                 acc_only<N, true>(s.p, s.m, acc);
 #pragma unroll
                 for (int b = 1; b < N; b++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) s.v[b][c] += hby2 * acc[b][c];
+                    for (int c = 0; c < 3; c++) s.v[b][c] = __builtin_fma(hby2, acc[b][c], s.v[b][c]);
                 mvs_drift(s, hby2, inv_m0);
                 s.t += 2.0 * hby2;
             } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
@@ -573,9 +425,24 @@ static int launch_n(const LaunchCtx &c) {
     return check_launch("propagator kernel launch");
 }
 
+// One lane per body pays while the ensemble is too small to fill the chip with wavefronts of whole systems
+// (kernels_mvs_body.hip).  Crossovers measured with WORKLOAD=c4 tools/lane_sweep.sh (profiles/r2/mvs_lane_sweep.txt):
+// nsys ~ 8k for nbod 3, 32k for nbod 4, 24-32k for nbod 5..10; below 4096 systems the lane-per-body kernel is 1.5x
+// (nbod 4) to 3.6x (nbod 10) faster.  Limits sit at the last grid point where it still wins.
+static bool small_mvs_ensemble(const LaunchCtx &c) {
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 32768, 24576, 24576, 24576, 24576, 20480, 24576};
+    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+}
+
 int launch_generic(const LaunchCtx &c, int integrator) {
     switch (integrator) {
-    case SWARM_HIP_MVS:
+    case SWARM_HIP_MVS: {
+        // small ensembles with nothing to monitor, or only stop_on_ejection's deactivation (no records, no printf)
+        const int variant = monitor_variant(c.mp);
+        const bool body_ok =
+            variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
+        if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_mvs_ensemble(c)))) return launch_mvs_body(c);
+    }
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
         break;
     case SWARM_HIP_EULER:

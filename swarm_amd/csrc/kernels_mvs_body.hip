@@ -1,0 +1,246 @@
+// kernels_mvs_body.hip -- the MVS propagator (propagators/mvs.hpp, keplerian.hpp) with ONE LANE PER BODY, for small
+// ensembles.
+//
+// The one-lane-per-system kernel (kernels_generic.hip) needs >= 131072 systems to give every SIMD its two wavefronts;
+// below that a launch lasts as long as one wave's chain of dependent steps whatever nsys is, and most of that chain
+// is the Kepler solver of one planet after the other.  Here the nbod bodies of a system sit in nbod adjacent lanes
+// (floor(64/nbod) systems per wavefront, one wavefront per workgroup): every planet's lane solves its own Kepler
+// problem, all at once, and sums the accelerations of its nbod-2 fellow planets, whose positions it reads from the
+// partner lanes (ds_bpermute); the star's lane carries the barycentre and otherwise rides along.  The sums over all
+// bodies of a system (coordinate changes, the star's drift) are formed by every lane of the system, in index order.
+//
+// Arithmetic is that of the lane-per-system kernel operation for operation: mvs_common.hpp holds the solver for both,
+// the sums run in the same order with the same fused operations, and a planet accumulates its partners in increasing
+// index order (for a pair the two signs of acc_only<N, true> cancel: fma(-d, -s, a) == fma(d, s, a)).  Both kernels
+// give bit-identical ensembles (tests/test_gpu_mvs_body.py).
+// Used by launch_generic for the no-op monitor (MVS.cfg as shipped) and, EJ = true, for stop_on_ejection with
+// deactivate_on_ejection only (nothing to log or print): every lane tests its own planet in the propagator's
+// coordinates (generic_gpu_bppt_integrator.hpp:189-224 calls the monitor between init() and shutdown()).
+#include "launch.hpp"
+#include "mvs_common.hpp"
+
+namespace swh {
+
+template <int N, bool EJ>
+__global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
+    constexpr int G = W / N; // systems per wavefront
+    const int lane = threadIdx.x;
+    const int g = lane / N, b = lane - g * N;
+    const long long sys_ll = (long long)blockIdx.x * G + g;
+    const bool valid = lane < G * N && sys_ll < e.nsys;
+    const int sys = valid ? (int)sys_ll : 0;
+    const int base = valid ? g * N : 0;      // first lane of my system (idle lanes read system 0 of the wave)
+    const unsigned long long group_mask = ((1ull << N) - 1) << base;
+
+    const size_t chunk = sys / W, sl = sys % W;
+    double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
+    double p[3], v[3], m[N], t = 0.0;
+    int state = SWARM_HIP_DISABLED;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
+        v[c] = valid ? row[(3 + c) * W] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+    if (valid) {
+        t = e.sysd[chunk * e.nsf * W + sl];
+        state = e.sysi[chunk * 2 * W + sl];
+    }
+    double m_own = m[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) m_own = b == j ? m[j] : m_own;
+
+    double mo[N - 2 > 0 ? N - 2 : 1]; // the fellow planets' masses, in increasing index order
+#pragma unroll
+    for (int q = 0; q < N - 2; q++) {
+        const int k = (q + 1 < b) ? q + 1 : q + 2;
+        mo[q] = m[1];
+#pragma unroll
+        for (int j = 2; j < N; j++) mo[q] = k == j ? m[j] : mo[q];
+    }
+
+    const bool mine = valid && state == SWARM_HIP_ACTIVE; // only these systems are converted, integrated and stored
+    const bool planet = mine && b >= 1;                   // this lane carries a planet that is being integrated
+    bool live = mine;
+    unsigned long long steps = 0;
+
+    // MVSPropagator::convert_std_to_internal_coord / convert_internal_to_std_coord, mvs.hpp:159-190, 195-230
+    // (mvs_to_internal / mvs_to_std of kernels_generic.hip: same sums, same order)
+    auto to_internal = [&]() {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double pc0 = __shfl(p[c], base);
+            double sump = 0., sumv = 0., mtot = 0.;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                mtot += m[j];
+                sump = __builtin_fma(m[j], __shfl(p[c], base + j), sump);
+                sumv = __builtin_fma(m[j], __shfl(v[c], base + j), sumv);
+            }
+            sumv /= mtot;
+            const double cp = sump / mtot;
+            if (mine) {
+                v[c] = b == 0 ? sumv : v[c] - sumv;
+                p[c] = b == 0 ? cp : p[c] - pc0;
+            }
+        }
+    };
+    auto to_std = [&]() {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double sump = 0., sumv = 0.;
+            const double m0 = m[0], pc0 = __shfl(p[c], base), vc0 = __shfl(v[c], base);
+            double mtot = m0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                mtot += m[j];
+                sump = __builtin_fma(m[j], __shfl(p[c], base + j), sump);
+                sumv = __builtin_fma(m[j], __shfl(v[c], base + j), sumv);
+            }
+            sump /= mtot;
+            const double dv0 = sumv / m0, dp = pc0 - sump;
+            if (mine) {
+                p[c] = b == 0 ? p[c] - sump : p[c] + dp;
+                v[c] = b == 0 ? v[c] - dv0 : v[c] + vc0;
+            }
+        }
+    };
+    // MVSPropagator::drift_step, mvs.hpp:242-256 (mvs_drift)
+    auto drift = [&](const double hby2, const double inv_m0) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double mv = 0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) mv = __builtin_fma(m[j], __shfl(v[c], base + j), mv);
+            const double shift = (mv * hby2) * inv_m0;
+            p[c] = b == 0 ? __builtin_fma(hby2, v[c], p[c]) : p[c] + shift;
+        }
+    };
+    // GravitationAcc::sum_acc_planets (gravitation_acc.hpp:96-139) for my planet; acc_only<N, true>
+    auto planet_forces = [&](double (&a)[3]) {
+        a[0] = a[1] = a[2] = 0.0;
+#pragma unroll
+        for (int q = 0; q < N - 2; q++) {
+            const int src = base + ((q + 1 < b) ? q + 1 : q + 2); // fellow planets in increasing index order
+            const double d0 = __shfl(p[0], src) - p[0], d1 = __shfl(p[1], src) - p[1], d2 = __shfl(p[2], src) - p[2];
+            const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+            const double y = rsqrt_full(r2);
+            const double rinv = y * (y * y);
+            const double sc = rinv * mo[q];
+            a[0] = __builtin_fma(d0, sc, a[0]);
+            a[1] = __builtin_fma(d1, sc, a[1]);
+            a[2] = __builtin_fma(d2, sc, a[2]);
+        }
+        if (!planet) a[0] = a[1] = a[2] = 0.0; // the star is not kicked
+    };
+    // drift_kepler of my planet (the star's and idle lanes go through the same instructions and discard)
+    auto kepler = [&](const KeplerConsts &k) {
+        KeplerOrbit o;
+        kepler_begin(o, p, v, k);
+        o.live = planet;
+        double y, S, C;
+        auto stumpff = [&]() {
+            y = kepler_y(o);
+            if (__builtin_expect(__all(!planet || fabs(y) < 1e-4), 1)) {
+                SC_series(y, S, C);
+            } else {
+                double sc[2];
+                SC_prussing_outlined(planet ? y : 0.0, sc);
+                S = sc[0], C = sc[1];
+            }
+        };
+        for (int i = 0; i < 7; i++) {
+            if (!__any(kepler_more(o, i))) break;
+            stumpff();
+            kepler_pass(o, k, y, S, C);
+        }
+        stumpff();
+        double np[3] = {p[0], p[1], p[2]}, nv[3] = {v[0], v[1], v[2]};
+        kepler_end(o, k, y, S, C, ip.kepler_compensated != 0, planet, np, nv);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            p[c] = planet ? np[c] : p[c];
+            v[c] = planet ? nv[c] : v[c];
+        }
+    };
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    auto ejection_monitor = [&](const bool take_part) {
+        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+        const bool met = (__ballot(ej) & group_mask) != 0;
+        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+    };
+
+    if (__any(mine)) {
+        const double dest = ip.destination_time;
+        const double inv_m0 = 1.0 / m[0];
+        KeplerConsts kc;
+        kc.set_star(sqrt(m[0]));
+        double acc[3];
+        // prop.init()
+        to_internal();
+        planet_forces(acc);
+        // Every lane walks through every step of the slowest system of its wave (the shuffles need all lanes); the
+        // lanes of a finished or idle system take steps of h = 0, which leave their registers as they are.
+        for (int iter = 0; iter < ip.max_iterations && __any(live); iter++) {
+            double max_timestep;
+            {
+#pragma clang fp contract(off)
+                max_timestep = dest - t;
+            }
+            // MVSPropagator::advance, mvs.hpp:260-293
+            const double hby2 = live ? 0.5 * fmin(max_timestep, ip.time_step) : 0.0;
+            drift(hby2, inv_m0);
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = __builtin_fma(hby2, acc[c], v[c]);
+            kc.set_dt(2.0 * hby2);
+            kepler(kc);
+            planet_forces(acc);
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = __builtin_fma(hby2, acc[c], v[c]);
+            drift(hby2, inv_m0);
+            t += 2.0 * hby2;
+            if (live) steps++;
+            if (EJ) ejection_monitor(live); // generic_gpu_bppt_integrator.hpp:189-224, in the propagator's coordinates
+            if (live && state == SWARM_HIP_ACTIVE && t >= dest) state = SWARM_HIP_INACTIVE;
+            live = live && state == SWARM_HIP_ACTIVE;
+        }
+        // prop.shutdown()
+        to_std();
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                row[c * W] = p[c];
+                row[(3 + c) * W] = v[c];
+            }
+            if (b == 0) {
+                e.sysd[chunk * e.nsf * W + sl] = t;
+                e.sysi[chunk * 2 * W + sl] = state;
+            }
+        }
+    }
+    if (valid && b == 0) {
+        if (cnt.accepted) cnt.accepted[sys] += steps;
+        if (cnt.attempted) cnt.attempted[sys] += steps;
+    }
+}
+
+// one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
+template <int N>
+static int launch_body_n(const LaunchCtx &c) {
+    constexpr int G = W / N;
+    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    if (monitor_variant(c.mp) != MON_OFF)
+        hipLaunchKernelGGL((mvs_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+    else
+        hipLaunchKernelGGL((mvs_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+    return check_launch("mvs (lane per body) kernel launch");
+}
+
+int launch_mvs_body(const LaunchCtx &c) {
+    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N>(c)));
+    return SWARM_HIP_OK;
+}
+
+} // namespace swh
