@@ -22,6 +22,7 @@ namespace swh {
 template <int N, bool EJ, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
+    constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM;
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     const long long sys_ll = (long long)blockIdx.x * G + g;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             c0[c] = k.kp_j0 * j0[c];
             pp[c] = __builtin_fma(k.kp_a, a0[c], pp[c]);
             dd0[c] = __builtin_fma(k.kv_a, a0[c], k.kv_j0 * j0[c]);
+            if (FOLD) pv[c] = pv[c] + dd0[c]; // hermite_step<N>'s form from nbod 9 on
         }
         double a1[3], j1[3];
 #pragma unroll
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 p[c] = __builtin_fma(-k.kp_a, a1[c], pp[c]) + __builtin_fma(k.kp_j1, j1[c], c0[c]);
-                v[c] = pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
+                v[c] = FOLD ? pv[c] + __builtin_fma(-k.kv_a, a1[c], k.kv_j1 * j1[c])
+                            : pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
             }
         }
         auto end_test = [&]() {
