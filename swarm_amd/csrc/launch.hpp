@@ -32,6 +32,7 @@ int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules);
 int launch_irk2_s2(const LaunchCtx &c, bool cpu_rules); // one object per stage count, kernels_irk2.hip
 int launch_irk2_s4(const LaunchCtx &c, bool cpu_rules);
 int launch_irk2_s6(const LaunchCtx &c, bool cpu_rules);
+int launch_irk2_body(const LaunchCtx &c, int method, bool cpu_rules); // one lane per body (kernels_irk2_body.hip)
 
 // nbod -> template dispatch, the analogue of choose<> (swarm/gpu/helpers.hpp:97-107,216-238)
 #ifdef SWH_DISPATCH_ONLY /* kernel experiments: instantiate one nbod only (-DSWH_DISPATCH_ONLY=3), never in the shipped build */
