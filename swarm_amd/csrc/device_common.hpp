@@ -60,6 +60,19 @@ struct IntParams {
     int kepler_compensated; // swarm_hip_launch_t::kepler_compensated (mvs)
 };
 
+// compile-time loop: f(IntC<0>{}), ..., f(IntC<N-1>{})
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int N>
 struct State {

@@ -10,35 +10,12 @@
 // p6^2, v6^2 in the global ensemble (L221) until the next force evaluation overwrites them, so a
 // launch whose budget ends on a reject hands back squares.  Here state is only written from the
 // last ACCEPTED step.
+#include <climits>
+
 #include "launch.hpp"
+#include "rkck_common.hpp"
 
 namespace swh {
-
-// Cash-Karp tableau, rkck_integrator.hpp:96-108 (row k = coefficients of stage k+1)
-struct CK {
-    static constexpr double b[6][6] = {
-        {0, 0, 0, 0, 0, 0},
-        {1.0 / 5.0, 0, 0, 0, 0, 0},
-        {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0},
-        {0.3, -0.9, 1.2, 0, 0, 0},
-        {-11.0 / 54.0, 2.5, -70.0 / 27.0, 35.0 / 27.0, 0, 0},
-        {1631.0 / 55296.0, 175.0 / 512.0, 575.0 / 13824.0, 44275.0 / 110592.0, 253.0 / 4096.0, 0}};
-    static constexpr double b6[6] = {37.0 / 378.0, 0, 250.0 / 621.0, 125.0 / 594.0, 0, 512.0 / 1771.0};
-    static constexpr double ecc[6] = {37.0 / 378.0 - 2825.0 / 27648.0, 0.0, 250.0 / 621.0 - 18575.0 / 48384.0,
-                                      125.0 / 594.0 - 13525.0 / 55296.0, -277.00 / 14336.0, 512.0 / 1771.0 - 0.25};
-    // weights w (length 6) over stage velocities k_vel[i] = vel + h * sum_j b[i][j] k_acc[j]:
-    //   sum_i w[i] k_vel[i] = rowsum(w) * vel + h * sum_j second(w, j) * k_acc[j]
-    static constexpr double rowsum(const double (&w)[6], int n) {
-        double s = 0;
-        for (int i = 0; i < n; i++) s += w[i];
-        return s;
-    }
-    static constexpr double second(const double (&w)[6], int n, int j) {
-        double s = 0;
-        for (int i = 0; i < n; i++) s += w[i] * b[i][j];
-        return s;
-    }
-};
 
 // The reference keeps k_vel[1..6] and k_acc[1..6] per (body,component) in registers of 3*nbod
 // threads.  With one lane per system that is 12 * 3 * nbod doubles per lane (nbod=6: 432 VGPRs)
@@ -99,7 +76,8 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 #pragma unroll
             for (int c = 0; c < 3; c++) sp[b][c] = s.p[b][c];
 
-        // stages 1..6: ka[k] = acc(p_k); p_{k+1} from (pos, vel, ka[0..k])
+        // stages 1..6: ka[k] = acc(p_k); p_{k+1} from (pos, vel, ka[0..k-1]) -- the operations of rkck_stage_position<k>
+        // (rkck_common.hpp) in place: through the helper the same instructions schedule 1.3 % slower here (C3, A/B)
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             acc_only<N, false>(sp, s.m, ka[k]);
@@ -126,9 +104,10 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
         double max_error = 0;
 #pragma unroll
         for (int b = 0; b < N; b++) {
-            double pem = 0, vem = 0, pm = 0, vm = 0;
+            double pe[3], ve[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
+                // (the operations of rkck_solution<ADAPTIVE>, rkck_common.hpp, in place)
                 double sa = 0, sa2 = 0, ea = 0, ea2 = 0;
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
@@ -143,51 +122,14 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
                 v6[b][c] = __builtin_fma(h, sa, s.v[b][c]);
                 p6[b][c] = __builtin_fma(h * h, sa2, __builtin_fma(CK::rowsum(CK::b6, 6) * h, s.v[b][c], s.p[b][c]));
                 if (ADAPTIVE) {
-                    const double ve = h * ea;
-                    const double pe = __builtin_fma(h * h, ea2, (CK::rowsum(CK::ecc, 6) * h) * s.v[b][c]);
-                    pem = (c == 0) ? pe * pe : pem + pe * pe;
-                    vem = (c == 0) ? ve * ve : vem + ve * ve;
-                    pm = (c == 0) ? p6[b][c] * p6[b][c] : pm + p6[b][c] * p6[b][c];
-                    vm = (c == 0) ? v6[b][c] * v6[b][c] : vm + v6[b][c] * v6[b][c];
+                    ve[c] = h * ea;
+                    pe[c] = __builtin_fma(h * h, ea2, (CK::rowsum(CK::ecc, 6) * h) * s.v[b][c]);
                 }
             }
-            if (ADAPTIVE) {
-                // L232-238; quotients through the 1-ulp reciprocal path: the estimate itself is a difference of
-                // nearly equal sums and is good to a few digits only
-                const double pen = fdiv(pem, pm), ven = fdiv(vem, vm);
-                max_error = fmax(fmax(pen, ven), max_error);
-            }
+            if (ADAPTIVE) max_error = fmax(rkck_body_error(pe, ve, p6[b], v6[b]), max_error); // L232-238
         }
         bool accept_step = true;
-        if (ADAPTIVE) { // L204-269: float constants, pow() on the normalised error
-            const float step_grow_power = -1. / (5 + 1.);
-            const float step_shrink_power = -1. / 5;
-            const float step_guess_safety_factor = 0.9;
-            const float step_grow_max_factor = 5.0;
-            const float step_shrink_min_factor = 0.2;
-            const double normalized_error = max_error / ip.error_tolerance;
-            // Cruising at the cap: for normalized_error < 0.25 the grow factor 0.9f * pow(e, -0.0833..) lies in
-            // [1.0102, inf] (e = 0 gives inf, clamped to 5), so time_step * factor >= time_step * 1.01 and, once
-            // that reaches max_time_step, the fmin below returns max_time_step whatever pow() says: the same value
-            // without the 226 instructions of pow().  Waves whose lanes all cruise skip them (C3: every step).
-            const bool capped = (normalized_error < 0.25) && (time_step * 1.01 >= ip.max_time_step);
-            double new_time_step = ip.max_time_step;
-            if (!capped) {
-                const double step_guess_power = (normalized_error < 1.) ? step_grow_power : step_shrink_power;
-                const double step_change_factor =
-                    ((normalized_error < 0.5) || (normalized_error > 1.0))
-                        ? step_guess_safety_factor * pow(normalized_error, 0.5 * step_guess_power)
-                        : 1.0;
-                new_time_step =
-                    (normalized_error > 1.)
-                        ? fmax(time_step * fmax(step_change_factor, (double)step_shrink_min_factor),
-                               ip.min_time_step)
-                        : fmin(time_step * fmax(fmin(step_change_factor, (double)step_grow_max_factor), 1.0),
-                               ip.max_time_step);
-            }
-            accept_step = (normalized_error < 1.0) || (fabs(time_step - new_time_step) < 1e-10);
-            time_step = new_time_step;
-        }
+        if (ADAPTIVE) accept_step = rkck_step_control(max_error, time_step, ip); // L204-269
         if (ADAPTIVE) accept_step = accept_step && live;
         if (live) attempted++;
         if (accept_step) {
@@ -252,7 +194,21 @@ static int launch_n(const LaunchCtx &c) {
     return check_launch("rkck kernel launch");
 }
 
+// One lane per body (kernels_rkck_body.hip) pays while the ensemble is too small to fill the chip with wavefronts of
+// whole systems, and at nbod 9 and 10 -- where the six stage accelerations of all bodies spill to scratch with one lane
+// per system -- at every size (65536 systems: 156 -> 69 ms and 196 -> 86 ms per 200 attempts).  Crossovers measured
+// with WORKLOAD=c3 tools/lane_sweep.sh (profiles/r2/rkck_lane_sweep.txt); below 8192 systems the lane-per-body kernel
+// is 1.2x (nbod 3) to 13x (nbod 10) faster.
+static bool small_rkck_ensemble(const LaunchCtx &c) {
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 20480, 24576, 20480, 32768, 40960, INT_MAX, INT_MAX};
+    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+}
+
 int launch_rkck(const LaunchCtx &c, bool adaptive) {
+    // small ensembles with nothing to monitor, or only stop_on_ejection's deactivation (no records, no printf)
+    const int variant = monitor_variant(c.mp);
+    const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
+    if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_rkck_ensemble(c)))) return launch_rkck_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {

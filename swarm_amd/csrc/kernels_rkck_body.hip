@@ -1,0 +1,182 @@
+// kernels_rkck_body.hip -- Cash-Karp Runge-Kutta (integrators/rkck_integrator.hpp:90-294, fixed and adaptive step) with
+// ONE LANE PER BODY, for small ensembles.
+//
+// With one lane per system (kernels_rkck.hip) an attempt is one chain of six force evaluations over all pairs, and the
+// six stage accelerations of all bodies (108 doubles at nbod 6) go through AGPRs; below one wavefront per SIMD the
+// run time is that chain's latency whatever nsys is.  Here the nbod bodies of a system sit in nbod adjacent lanes
+// (floor(64/nbod) systems per wavefront, one wavefront per workgroup): a lane keeps the 18 stage accelerations of its
+// own body, evaluates the force on it from its partners' stage positions (ds_bpermute) and forms its own stage
+// positions, solution and error estimate; the system's normalised error is the maximum over its lanes, and every lane
+// of a system runs the same step control on it.  The reference's kernel is laid out the same way one level finer
+// (3 nbod threads per system, L90-131).
+//
+// Arithmetic is that of the lane-per-system kernel operation for operation (rkck_common.hpp holds everything but the
+// forces for both; forces accumulate the partners in increasing index order and the two signs of a pair in acc_only
+// cancel), so both kernels give bit-identical ensembles, step sizes and accept/reject sequences
+// (tests/test_gpu_rkck_body.py).  Serves the no-op monitor and stop_on_ejection with deactivate_on_ejection alone.
+#include "launch.hpp"
+#include "rkck_common.hpp"
+
+namespace swh {
+
+template <int N, bool ADAPTIVE, bool EJ>
+__global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
+    constexpr int G = W / N; // systems per wavefront
+    const int lane = threadIdx.x;
+    const int g = lane / N, b = lane - g * N;
+    const long long sys_ll = (long long)blockIdx.x * G + g;
+    const bool valid = lane < G * N && sys_ll < e.nsys;
+    const int sys = valid ? (int)sys_ll : 0;
+    const int base = valid ? g * N : 0; // first lane of my system (idle lanes read system 0 of the wave)
+    const unsigned long long group_mask = ((1ull << N) - 1) << base;
+
+    const size_t chunk = sys / W, sl = sys % W;
+    double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
+    double p[3], v[3], mo[N - 1], t = 0.0;
+    int state = SWARM_HIP_DISABLED;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
+        v[c] = valid ? row[(3 + c) * W] : 0.0;
+    }
+    const double m_own = valid ? row[6 * W] : 1.0;
+#pragma unroll
+    for (int q = 0; q < N - 1; q++) {
+        const int j = q < b ? q : q + 1; // partners in increasing index order
+        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+    }
+    if (valid) {
+        t = e.sysd[chunk * e.nsf * W + sl];
+        state = e.sysi[chunk * 2 * W + sl];
+    }
+    const int state_in = state;
+
+    // the force on my body with all bodies at `pos` (acc_only<N, false>); wave-wide, no divergence inside
+    auto force = [&](const double (&pos)[3], double (&a)[3]) {
+        a[0] = a[1] = a[2] = 0.0;
+#pragma unroll
+        for (int q = 0; q < N - 1; q++) {
+            const int src = base + (q < b ? q : q + 1);
+            const double d0 = __shfl(pos[0], src) - pos[0], d1 = __shfl(pos[1], src) - pos[1],
+                         d2 = __shfl(pos[2], src) - pos[2];
+            const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+            const double y = rsqrt_full(r2);
+            const double rinv = y * (y * y);
+            const double sc = rinv * mo[q];
+            a[0] = __builtin_fma(d0, sc, a[0]);
+            a[1] = __builtin_fma(d1, sc, a[1]);
+            a[2] = __builtin_fma(d2, sc, a[2]);
+        }
+    };
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    auto ejection_monitor = [&](const bool take_part) {
+        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+        const bool met = (__ballot(ej) & group_mask) != 0;
+        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+    };
+    if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
+
+    const int iteration_count = (int)(ip.destination_time / ip.max_time_step); // L75
+    const double dest = ip.destination_time;
+    double time_step = ip.max_time_step; // L133
+    unsigned long long accepted = 0, attempted = 0;
+
+    // Every lane goes through every attempt of the slowest system of its wave (the shuffles need all lanes); a system
+    // that is done, or was not ACTIVE at launch, never commits.
+    bool live = valid && state == SWARM_HIP_ACTIVE;
+    for (int iter = 0; iter < iteration_count && __any(live); iter++) {
+        double h = time_step;
+        {
+#pragma clang fp contract(off)
+            if (t + h > dest) h = dest - t;
+        }
+        double ka[6][3], sp[3] = {p[0], p[1], p[2]};
+        // stages 1..6: ka[k] = acc(p_k); p_{k+1} from (pos, vel, ka[0..k-1])
+        static_for<6>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            force(sp, ka[k]);
+            if constexpr (k < 5) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double kc[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) kc[j] = j < k ? ka[j][c] : 0.0;
+                    sp[c] = rkck_stage_position<k>(h, p[c], v[c], kc);
+                }
+            }
+        });
+        // 5th-order solution and the embedded error estimate of my body (L193-199, L232-238)
+        double p6[3], v6[3], pe[3], ve[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double kc[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) kc[j] = ka[j][c];
+            rkck_solution<ADAPTIVE>(h, p[c], v[c], kc, p6[c], v6[c], pe[c], ve[c]);
+        }
+        bool accept_step = true;
+        if (ADAPTIVE) {
+            const double mine = rkck_body_error(pe, ve, p6, v6);
+            double max_error = 0;
+#pragma unroll
+            for (int j = 0; j < N; j++) max_error = fmax(__shfl(mine, base + j), max_error);
+            accept_step = rkck_step_control(max_error, time_step, ip); // L204-269, the same in every lane of the system
+        }
+        const bool stepped = accept_step && live;
+        if (live) attempted++;
+        if (stepped) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) p[c] = p6[c], v[c] = v6[c];
+            t += h;
+            accepted++;
+        }
+        if (EJ) ejection_monitor(stepped); // the monitor runs for systems that accepted (L283); wave-wide ballot
+        if (stepped && state == SWARM_HIP_ACTIVE && t >= dest) state = SWARM_HIP_INACTIVE;
+        live = live && state == SWARM_HIP_ACTIVE;
+    }
+    if (valid && (accepted || state != state_in)) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            row[c * W] = p[c];
+            row[(3 + c) * W] = v[c];
+        }
+        if (b == 0) {
+            e.sysd[chunk * e.nsf * W + sl] = t;
+            e.sysi[chunk * 2 * W + sl] = state;
+        }
+    }
+    if (valid && b == 0) {
+        if (cnt.accepted) cnt.accepted[sys] += accepted;
+        if (cnt.attempted) cnt.attempted[sys] += attempted;
+    }
+}
+
+// one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
+template <int N>
+static int launch_body_n(const LaunchCtx &c, bool adaptive) {
+    constexpr int G = W / N;
+    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    const bool ej = monitor_variant(c.mp) != MON_OFF;
+#define SWH_LAUNCH_BODY(AD, EJ) \
+    hipLaunchKernelGGL((rkck_body_kernel<N, AD, EJ>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt)
+    if (adaptive) {
+        if (ej)
+            SWH_LAUNCH_BODY(true, true);
+        else
+            SWH_LAUNCH_BODY(true, false);
+    } else {
+        if (ej)
+            SWH_LAUNCH_BODY(false, true);
+        else
+            SWH_LAUNCH_BODY(false, false);
+    }
+#undef SWH_LAUNCH_BODY
+    return check_launch("rkck (lane per body) kernel launch");
+}
+
+int launch_rkck_body(const LaunchCtx &c, bool adaptive) {
+    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N>(c, adaptive)));
+    return SWARM_HIP_OK;
+}
+
+} // namespace swh

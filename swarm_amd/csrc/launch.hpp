@@ -25,6 +25,7 @@ int launch_hermite(const LaunchCtx &c, bool adaptive);
 int launch_hermite_body(const LaunchCtx &c, bool adaptive); // one lane per body, small ensembles (kernels_hermite_body.hip)
 int launch_hermite_mce(const LaunchCtx &c); // `hermite` + mce_stat (plugins/hermite.cu:40)
 int launch_rkck(const LaunchCtx &c, bool adaptive);
+int launch_rkck_body(const LaunchCtx &c, bool adaptive); // one lane per body, small ensembles (kernels_rkck_body.hip)
 int launch_generic(const LaunchCtx &c, int integrator);
 int launch_mvs_body(const LaunchCtx &c); // one lane per body, small ensembles (kernels_mvs_body.hip)
 // Gauss IRK; method = stages (2, 4, 6); cpu_rules = irk2_cpu's iteration constants and failure rule

@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--T", type=float)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--lane-mode", type=int, default=0, help="0 auto, 1 lane per system, 2 lane per body (hermite, hermite_adap, mvs, irk2)")
+    ap.add_argument("--lane-mode", type=int, default=0, help="0 auto, 1 lane per system, 2 lane per body (hermite, hermite_adap, mvs, irk2, rkck)")
     ap.add_argument("--spread", type=float, default=0.0, help="scale systems geometrically by up to this factor")
     ap.add_argument("--shuffle", action="store_true", help="c3_div: systems in random order")
     ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
