@@ -378,6 +378,55 @@ __device__ __forceinline__ void log_system(const LogBuf &lg, const State<N> &s, 
     snapshot_fill<N>(lg.buf + off, s.t, s.id, s.state, s.p, s.v, s.m);
 }
 
+// The same record written by the N lanes of a system in the lane-per-body kernels: the star's lanes of the systems
+// that log in this step reserve together (one atomic per wavefront), every lane writes its own body's 64 bytes and the
+// star's lane the 32-byte header.  Called by the whole wavefront; `want` is the same in all lanes of a system,
+// `star` = the lane of the system's body 0, `b` = my body.
+template <int N>
+__device__ __forceinline__ void log_system_body(const LogBuf &lg, const bool want, const int b, const int star,
+                                                const double t, const int id, const int state, const double (&p)[3],
+                                                const double (&v)[3], const double m) {
+    const int len = snapshot_len(N);
+    const unsigned long long mask = __ballot(want && b == 0);
+    if (mask == 0) return;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    const int cnt = __popcll(mask);
+    int base = 0;
+    if (lane == leader && lg.buf) base = atomicAdd(lg.cursor, cnt * len);
+    base = __shfl(base, leader);
+    if (!want) return;
+    const int rank = __popcll(mask & ((1ull << star) - 1ull));
+    const long long off = (long long)base + (long long)rank * len;
+    if (!lg.buf || off + len > (long long)lg.cap) {
+        // overflow: give the bytes back and count the drop (the reference drops silently)
+        if (b == 0) {
+            if (lg.buf) atomicSub(lg.cursor, len);
+            if (lg.cursor) atomicAdd(lg.cursor + 1, 1);
+        }
+        return;
+    }
+    uint8_t *r = lg.buf + off;
+    double *rd = reinterpret_cast<double *>(r);
+    if (b == 0) {
+        int32_t *ri = reinterpret_cast<int32_t *>(r);
+        ri[0] = 1; // EVT_SNAPSHOT
+        ri[1] = len;
+        rd[1] = t;
+        ri[4] = id;
+        ri[5] = state;
+        ri[6] = N;
+        ri[7] = 0;
+        for (int k = (32 + 64 * N) / 8; k < len / 8; k++) rd[k] = 0.0; // pad to 16
+    }
+    double *q = rd + 4 + 8 * b;
+    q[0] = p[0], q[1] = p[1], q[2] = p[2];
+    q[3] = v[0], q[4] = v[1], q[5] = v[2];
+    q[6] = m;
+    reinterpret_cast<int32_t *>(q + 7)[0] = b;
+    reinterpret_cast<int32_t *>(q + 7)[1] = 0;
+}
+
 // Per-lane reservation (bits/gpulog_write.h:14-22) for the rare records written from divergent
 // code: lprintf lines and the snapshots mce_stat writes in the middle of its pass.
 __device__ __forceinline__ uint8_t *log_reserve_lane(const LogBuf &lg, int len) {

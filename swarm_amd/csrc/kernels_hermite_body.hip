@@ -12,15 +12,20 @@
 // a body accumulates its partners in increasing index order, first term by multiplication, and
 // (p_j - p_i), (v_j - v_i) enter the pair quantities only through products that are even in the
 // sign, so both kernels give bit-identical ensembles (tests/test_gpu_hermite.py).
-// Used by launch_hermite for the no-op monitor (Hermite.cfg as shipped: no deactivate/log keys) and, EJ = true,
-// for stop_on_ejection with deactivate_on_ejection only (nothing to log or print): every lane tests its own
-// planet (stop_on_ejection.hpp:108-138) and the lanes of a system share the verdict through one ballot.
+// Used by launch_hermite for the no-op monitor (Hermite.cfg as shipped: no deactivate/log keys), MONB = 0; for
+// stop_on_ejection without printing, MONB = 1: every lane tests its own planet (stop_on_ejection.hpp:108-138), the
+// lanes of a system share the verdict through one ballot and, with log_on_ejection, write the snapshot record
+// together (log_system_body); and for log_time_interval, MONB = 2 (log_time_interval.hpp:98-119), every lane keeping
+// its system's next_log_time.
 #include "launch.hpp"
 
 namespace swh {
 
-template <int N, bool EJ, bool ADAPTIVE>
-__global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
+enum { MONB_OFF = 0, MONB_EJECTION = 1, MONB_LOG_INTERVAL = 2 };
+
+template <int N, int MONB, bool ADAPTIVE>
+__global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
+    constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     constexpr int G = W / N; // systems per wavefront
     constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM;
     const int lane = threadIdx.x;
@@ -35,6 +40,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
     double p[3], v[3], mo[N - 1], t = 0.0;
     const double m_own = (EJ && valid) ? row[6 * W] : 1.0;
+    const int id = (EJ && valid) ? e.sysi[(sys / W) * 2 * W + W + sys % W] : 0;
     const unsigned long long group_mask = ((1ull << N) - 1) << base; // lanes of my system (base + N <= 64 when valid)
     int state = SWARM_HIP_DISABLED;
 #pragma unroll
@@ -52,11 +58,23 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
         state = e.sysi[chunk * 2 * W + sl];
     }
     const int state_in = state;
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    // The monitor of one system, called by the whole wavefront.  stop_on_ejection: every lane tests its own planet,
+    // one ballot shares the verdict (pass_one), the state changes (pass_two), then the record (operator(), L140-146).
+    double next_log_time = t; // log_time_interval.hpp:118-119
     auto ejection_monitor = [&](const bool take_part) {
-        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-        const bool met = (__ballot(ej) & group_mask) != 0;
-        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+        bool want = false;
+        if (MONB == MONB_EJECTION) {
+            const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+            const bool met = (__ballot(ej) & group_mask) != 0;
+            if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+            want = take_part && met && mp.ej_log;
+            if (!mp.ej_log) return;
+        } else if (MONB == MONB_LOG_INTERVAL) {
+#pragma clang fp contract(off)
+            want = take_part && mp.log_interval != 0. && t >= next_log_time;
+            if (want) next_log_time += mp.log_interval;
+        }
+        log_system_body<N>(lg, want, b, base, t, id, state, p, v, m_own);
     };
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
     if (EJ && ADAPTIVE) ejection_monitor(valid);
@@ -188,19 +206,25 @@ template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-    const bool ej = monitor_variant(c.mp) != MON_OFF;
-#define SWH_LAUNCH_BODY(EJ, AD) \
-    hipLaunchKernelGGL((hermite_body_kernel<N, EJ, AD>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt)
+    const int monb = monitor_variant(c.mp) == MON_OFF ? MONB_OFF
+                     : c.mp.kind == SWARM_HIP_MON_LOG_INTERVAL ? MONB_LOG_INTERVAL
+                                                               : MONB_EJECTION;
+#define SWH_LAUNCH_BODY(M, AD)                                                                                         \
+    hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     if (adaptive) {
-        if (ej)
-            SWH_LAUNCH_BODY(true, true);
+        if (monb == MONB_EJECTION)
+            SWH_LAUNCH_BODY(MONB_EJECTION, true);
+        else if (monb == MONB_LOG_INTERVAL)
+            SWH_LAUNCH_BODY(MONB_LOG_INTERVAL, true);
         else
-            SWH_LAUNCH_BODY(false, true);
+            SWH_LAUNCH_BODY(MONB_OFF, true);
     } else {
-        if (ej)
-            SWH_LAUNCH_BODY(true, false);
+        if (monb == MONB_EJECTION)
+            SWH_LAUNCH_BODY(MONB_EJECTION, false);
+        else if (monb == MONB_LOG_INTERVAL)
+            SWH_LAUNCH_BODY(MONB_LOG_INTERVAL, false);
         else
-            SWH_LAUNCH_BODY(false, false);
+            SWH_LAUNCH_BODY(MONB_OFF, false);
     }
 #undef SWH_LAUNCH_BODY
     return check_launch("hermite (lane per body) kernel launch");
