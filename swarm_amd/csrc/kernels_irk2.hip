@@ -221,10 +221,9 @@ static bool irk2_prefers_body(const LaunchCtx &c) { return c.ens.nbod >= 4 || c.
 int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
     if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
         if (int rc = mce_check_attributes(c)) return rc;
-    // one lane per body (kernels_irk2_body.hip) with nothing to monitor, or only stop_on_ejection's deactivation
+    // one lane per body (kernels_irk2_body.hip) with nothing to monitor, or stop_on_ejection without printing
     const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT &&
-                         (monitor_is_noop(c.mp) || (monitor_variant(c.mp) == MON_ON &&
-                                                    c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log));
+                         (monitor_is_noop(c.mp) || (monitor_variant(c.mp) == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION));
     if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && irk2_prefers_body(c)))) return launch_irk2_body(c, method, cpu_rules);
     switch (method) {
     case 2: return launch_irk2_s2(c, cpu_rules);

@@ -15,7 +15,7 @@
 // cancel: fma(-d, -s, a) == fma(d, s, a)), so both kernels give bit-identical ensembles (tests/test_gpu_irk2_body.py).
 // Every lane walks through every sweep and every step of the slowest system of its wavefront (the shuffles need all
 // lanes); a system that has converged, finished or given up computes and discards.
-// Serves the no-op monitor and stop_on_ejection with deactivate_on_ejection alone (no records); the one message of
+// Serves the no-op monitor and stop_on_ejection without printing (deactivation, snapshot records); the one message of
 // the integrator itself, "no convergence of iteration", is printed by the star's lane.
 #include "irk2_common.hpp"
 #include "launch.hpp"
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
         v[c] = valid ? row[(3 + c) * W] : 0.0;
     }
     const double m_own = valid ? row[6 * W] : 1.0;
+    const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
 #pragma unroll
     for (int q = 0; q < N - 1; q++) {
         const int j = q < b ? q : q + 1; // partners in increasing index order
@@ -73,11 +74,13 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict; with
+    // log_on_ejection the lanes of the system write the snapshot record together (after the state change)
     auto ejection_monitor = [&](const bool take_part) {
         const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
         const bool met = (__ballot(ej) & group_mask) != 0;
         if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+        if (mp.ej_log) log_system_body<N>(lg, take_part && met, b, base, t, id, state, p, v, m_own);
     };
 
     unsigned long long steps = 0;

@@ -13,14 +13,14 @@
 // Arithmetic is that of the lane-per-system kernel operation for operation (rkck_common.hpp holds everything but the
 // forces for both; forces accumulate the partners in increasing index order and the two signs of a pair in acc_only
 // cancel), so both kernels give bit-identical ensembles, step sizes and accept/reject sequences
-// (tests/test_gpu_rkck_body.py).  Serves the no-op monitor and stop_on_ejection with deactivate_on_ejection alone.
+// (tests/test_gpu_rkck_body.py).  Serves the no-op monitor and stop_on_ejection without printing (deactivation, snapshot records).
 #include "launch.hpp"
 #include "rkck_common.hpp"
 
 namespace swh {
 
 template <int N, bool ADAPTIVE, bool EJ>
-__global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
+__global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
         v[c] = valid ? row[(3 + c) * W] : 0.0;
     }
     const double m_own = valid ? row[6 * W] : 1.0;
+    const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
 #pragma unroll
     for (int q = 0; q < N - 1; q++) {
         const int j = q < b ? q : q + 1; // partners in increasing index order
@@ -68,11 +69,13 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict; with
+    // log_on_ejection the lanes of the system write the snapshot record together (after the state change, L140-146)
     auto ejection_monitor = [&](const bool take_part) {
         const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
         const bool met = (__ballot(ej) & group_mask) != 0;
         if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+        if (mp.ej_log) log_system_body<N>(lg, take_part && met, b, base, t, id, state, p, v, m_own);
     };
     if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
 
@@ -158,7 +161,7 @@ static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
     const bool ej = monitor_variant(c.mp) != MON_OFF;
 #define SWH_LAUNCH_BODY(AD, EJ) \
-    hipLaunchKernelGGL((rkck_body_kernel<N, AD, EJ>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt)
+    hipLaunchKernelGGL((rkck_body_kernel<N, AD, EJ>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     if (adaptive) {
         if (ej)
             SWH_LAUNCH_BODY(true, true);

@@ -68,15 +68,22 @@ def test_log_time_interval_records_are_identical(gpu, oracle, name, cfg, nbod, n
     assert mine == ref
 
 
+EJECTING = {
+    "hermite_cpu": {"time_step": "0.02"},
+    "rkck_adaptive": {"min_time_step": "1e-5", "max_time_step": "0.25", "error_tolerance": "1e-20"},
+    "irk2_cpu": {"time_step": "0.25"},
+}
+
+
+@pytest.mark.parametrize("name", sorted(EJECTING))
 @pytest.mark.parametrize("nbod,nsys", [(3, 200), (6, 45)])
-def test_log_on_ejection_records_are_identical(gpu, oracle, nbod, nsys):
-    """stop_on_ejection with log_on_ejection (and deactivate_on_ejection): one record per ejected system, taken
-    after the state change (stop_on_ejection.hpp:140-146)."""
+def test_log_on_ejection_records_are_identical(gpu, oracle, name, nbod, nsys):
+    """stop_on_ejection with log_on_ejection (and deactivate_on_ejection) in the lane-per-body Hermite, Cash-Karp and
+    Gauss IRK kernels: one record per ejected system, taken after the state change (stop_on_ejection.hpp:140-146)."""
     S, O = gpu, oracle
     e = O.generate(nsys, nbod, spacing_factor=1.4 ** (1.0 / (nbod - 2)))   # circular orbits at r = 10 ... 14
     e.vel[:, 1:] *= np.linspace(0.9, 2.0, nsys)[:, None, None]
-    cfg = {"integrator": "hermite_cpu", "time_step": "0.02", "deactivate_on_ejection": "1", "log_on_ejection": "1",
-           "rmax": "21", "log_writer": "null"}
+    cfg = dict(EJECTING[name], integrator=name, deactivate_on_ejection="1", log_on_ejection="1", rmax="21")
     out = {}
     for mode in ("1", "2", "0"):
         out[mode] = run_logged(S, e, dict(cfg, lane_mode=mode), 60.0)
@@ -87,8 +94,10 @@ def test_log_on_ejection_records_are_identical(gpu, oracle, nbod, nsys):
     assert r1 == r2 == split(raw0)
     recs = O.parse_log(raw2)
     gone = h2.state == O.DISABLED
-    assert 0 < gone.sum() < nsys and len(recs) == gone.sum()
-    assert sorted(r["sys"] for r in recs) == sorted(int(i) for i in h2.id[gone])
+    # (rkck calls its monitor once more at the start of every launch, for every system whatever its state --
+    # rkck_integrator.hpp:140 -- so a system already disabled is logged again by the next launch)
+    assert 0 < gone.sum() < nsys and (len(recs) >= gone.sum() if name.startswith("rkck") else len(recs) == gone.sum())
+    assert sorted({r["sys"] for r in recs}) == sorted(int(i) for i in h2.id[gone])
     assert all(r["state"] == O.DISABLED for r in recs)
     for r in recs:                                      # the record is the system as it was stored
         i = r["sys"]
