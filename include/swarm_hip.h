@@ -124,11 +124,12 @@ typedef struct swarm_hip_launch {
     int32_t irk2_method;                   /* method= (irk2: stages 2, 4, 6; 0 = 6)      */
     int32_t log_transits;                  /* log_transits= (log_transit, default 1)     */
     int32_t log_occultations;              /* log_occultations= (default 0)              */
-    int32_t lane_mode;                     /* 0 = choose by nsys; 1 = one lane per system; 2 = one lane
+    int32_t lane_mode;                     /* 0 = choose by nbod and nsys; 1 = one lane per system; 2 = one lane
                                               per body (hermite, hermite_adap, mvs, rkck_*: small ensembles;
                                               irk2 from nbod 4 and rkck_* from nbod 9 on at every size; each
-                                              with a no-op monitor or stop_on_ejection's deactivation alone,
-                                              ignored elsewhere).  No reference key. */
+                                              with a no-op monitor or stop_on_ejection without printing,
+                                              hermite* also with log_time_interval; ignored elsewhere).
+                                              No reference key. */
     double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
                                               monitor's dt is time_step=                 */
     int32_t kepler_compensated;            /* kepler_compensated= (mvs; default 0; no reference key).  0: the f and g
