@@ -440,10 +440,9 @@ static bool small_mvs_ensemble(const LaunchCtx &c) {
 int launch_generic(const LaunchCtx &c, int integrator) {
     switch (integrator) {
     case SWARM_HIP_MVS: {
-        // small ensembles with nothing to monitor, or only stop_on_ejection's deactivation (no records, no printf)
+        // small ensembles with nothing to monitor, or stop_on_ejection without printing
         const int variant = monitor_variant(c.mp);
-        const bool body_ok =
-            variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION && !c.mp.ej_log);
+        const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION);
         if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_mvs_ensemble(c)))) return launch_mvs_body(c);
     }
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));

@@ -13,16 +13,16 @@
 // the sums run in the same order with the same fused operations, and a planet accumulates its partners in increasing
 // index order (for a pair the two signs of acc_only<N, true> cancel: fma(-d, -s, a) == fma(d, s, a)).  Both kernels
 // give bit-identical ensembles (tests/test_gpu_mvs_body.py).
-// Used by launch_generic for the no-op monitor (MVS.cfg as shipped) and, EJ = true, for stop_on_ejection with
-// deactivate_on_ejection only (nothing to log or print): every lane tests its own planet in the propagator's
-// coordinates (generic_gpu_bppt_integrator.hpp:189-224 calls the monitor between init() and shutdown()).
+// Used by launch_generic for the no-op monitor (MVS.cfg as shipped) and, EJ = true, for stop_on_ejection without
+// printing: every lane tests its own planet in the propagator's coordinates (generic_gpu_bppt_integrator.hpp:189-224
+// calls the monitor between init() and shutdown()); a system that logs is converted for the record and back.
 #include "launch.hpp"
 #include "mvs_common.hpp"
 
 namespace swh {
 
 template <int N, bool EJ>
-__global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, Counters cnt) {
+__global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
         t = e.sysd[chunk * e.nsf * W + sl];
         state = e.sysi[chunk * 2 * W + sl];
     }
+    const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
     double m_own = m[0];
 #pragma unroll
     for (int j = 1; j < N; j++) m_own = b == j ? m[j] : m_own;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 
     // MVSPropagator::convert_std_to_internal_coord / convert_internal_to_std_coord, mvs.hpp:159-190, 195-230
     // (mvs_to_internal / mvs_to_std of kernels_generic.hip: same sums, same order)
-    auto to_internal = [&]() {
+    auto to_internal = [&](const bool who) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double pc0 = __shfl(p[c], base);
@@ -80,13 +81,13 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             }
             sumv /= mtot;
             const double cp = sump / mtot;
-            if (mine) {
+            if (who) {
                 v[c] = b == 0 ? sumv : v[c] - sumv;
                 p[c] = b == 0 ? cp : p[c] - pc0;
             }
         }
     };
-    auto to_std = [&]() {
+    auto to_std = [&](const bool who) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             double sump = 0., sumv = 0.;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             }
             sump /= mtot;
             const double dv0 = sumv / m0, dp = pc0 - sump;
-            if (mine) {
+            if (who) {
                 p[c] = b == 0 ? p[c] - sump : p[c] + dp;
                 v[c] = b == 0 ? v[c] - dv0 : v[c] + vc0;
             }
@@ -165,11 +166,20 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             v[c] = planet ? nv[c] : v[c];
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict
+    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict.  A system that
+    // is to be logged goes to standard coordinates for the record and back, as generic_mon_call does it
+    // (generic_gpu_bppt_integrator.hpp:189-224: pass_one, conversion, pass_two, log, conversion back).
     auto ejection_monitor = [&](const bool take_part) {
         const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
         const bool met = (__ballot(ej) & group_mask) != 0;
+        const bool rec = take_part && met && mp.ej_log;
+        const bool any_rec = mp.ej_log && __any(rec);
+        if (any_rec) to_std(rec);
         if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+        if (any_rec) {
+            log_system_body<N>(lg, rec, b, base, t, id, state, p, v, m_own);
+            to_internal(rec);
+        }
     };
 
     if (__any(mine)) {
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
         kc.set_star(sqrt(m[0]));
         double acc[3];
         // prop.init()
-        to_internal();
+        to_internal(mine);
         planet_forces(acc);
         // Every lane walks through every step of the slowest system of its wave (the shuffles need all lanes); the
         // lanes of a finished or idle system take steps of h = 0, which leave their registers as they are.
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             live = live && state == SWARM_HIP_ACTIVE;
         }
         // prop.shutdown()
-        to_std();
+        to_std(mine);
         if (mine) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -232,9 +242,9 @@ static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
     if (monitor_variant(c.mp) != MON_OFF)
-        hipLaunchKernelGGL((mvs_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+        hipLaunchKernelGGL((mvs_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt);
     else
-        hipLaunchKernelGGL((mvs_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.cnt);
+        hipLaunchKernelGGL((mvs_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt);
     return check_launch("mvs (lane per body) kernel launch");
 }
 
