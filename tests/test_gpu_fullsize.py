@@ -148,3 +148,25 @@ def test_c5_full_size_hermite_adap_log_sampled(gpu, oracle):
         assert sid == r["sys"] and abs(t - r["time"]) <= 1e-12 * max(1.0, abs(t))
         bodies = rec[row, 32:32 + 64 * 4].copy().view(np.float64).reshape(4, 8)[:, :7]
         assert rel_diff(bodies[1:, :3], r["bodies"][1:, :3]) < 1e-10
+
+
+def test_irk2_full_size_lane_per_body_sampled(gpu, oracle):
+    """65536 x 6 through `irk2` (s = 6), which lane_mode=0 runs one lane per body at this nbod (kernels_irk2_body.hip):
+    the whole ensemble finishes, a sample of 128 systems against the oracle -- steps exact, coordinates 1e-10 -- and
+    the same sample bit-identical to the lane-per-system kernel run on it alone."""
+    S, O = gpu, oracle
+    nsys = 65536
+    e = perturbed(O, nsys, 6, seed=13, amp=2e-3)
+    h = to_host(S, e)
+    integ, _ = run(S, h, {"integrator": "irk2", "time_step": "0.01"}, 0.5)
+    idx = np.sort(np.random.default_rng(3).choice(nsys, 128, replace=False))
+    o = sample_of(O, e, idx)
+    acc, _ = O.integrate(o, O.params("irk2", 0.5, time_step=0.01), threads=8, counters=True)
+    gacc, _ = integ.step_counts()
+    assert (h.state == O.INACTIVE).all() and (gacc == 50).all()
+    assert (gacc[idx] == acc).all()
+    np.testing.assert_allclose(h.time[idx], o.time, rtol=0, atol=1e-12)
+    assert rel_diff(h.pos[idx, 1:], o.pos[:, 1:]) < 1e-10 and rel_diff(h.vel[idx, 1:], o.vel[:, 1:]) < 1e-10
+    s1 = to_host(S, sample_of(O, e, idx))
+    run(S, s1, {"integrator": "irk2", "time_step": "0.01", "lane_mode": "1"}, 0.5)
+    assert (s1.pos == h.pos[idx]).all() and (s1.vel == h.vel[idx]).all() and (s1.time == h.time[idx]).all()
