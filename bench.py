@@ -12,7 +12,8 @@ N > 1: one process per GPU (torchrun), the ensemble is partitioned by system ind
 integrates its own shard (no data-path collective); after the timed region the energy/ejection
 statistics are all-reduced and the final shards gathered over RCCL, outside the timing.
 
-At N = 1 the JSON line also carries a "secondary" block: BASELINE's other single-GPU configurations (C3
+At N = 1 the JSON line also carries a "lane_per_body" block (three small measurements of the DESIGN 3.9 kernels beside
+the lane-per-system ones) and a "secondary" block: BASELINE's other single-GPU configurations (C3
 rkck_adaptive 65536 x 6 in its cruising and its divergent regime, one C4 shard of mvs 131072 x 8, C5
 hermite_adap_log 65536 x 4), one or two launches each, kernel time by HIP events (tools/perf.py measure()).
 
@@ -68,6 +69,22 @@ def secondary_block():
         keep["ms_is"] = ("first launch of the run, HIP events on the launch stream; the same launch on a copy of the "
                          "ensemble is enqueued directly ahead of it so that it does not start at an idle clock")
         out[tag] = keep
+    return out
+
+
+def lane_per_body_block():
+    """The lane-per-body kernels beside the lane-per-system ones on the same ensembles: lane_mode=1
+    forced against lane_mode=0, the library's own choice (one lane per body in all three cases).  Kernel ms."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import perf
+    out = {}
+    for tag, workload, kw in (("irk2_65536x6_200_steps", "irk2", dict(nsys=65536, nbod=6, T=2.0)),
+                              ("mvs_4096x8_1001_steps", "c4", dict(nsys=4096)),
+                              ("rkck_adaptive_2048x6_100_attempts", "c3", dict(nsys=2048))):
+        ms = {}
+        for name, mode in (("lane_per_system_ms", 1), ("library_choice_ms", 0)):
+            ms[name] = perf.measure(workload, reps=2, host_to_host=False, warm=True, lane_mode=mode, **kw)["ms"]
+        out[tag] = ms
     return out
 
 
@@ -262,6 +279,7 @@ def main():
         out["gather_verified"] = bool(gather_ok)
     if rank == 0 and world == 1 and dist is None and not args.no_secondary:
         out["secondary"] = secondary_block()
+        out["lane_per_body"] = lane_per_body_block()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
