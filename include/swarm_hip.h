@@ -128,7 +128,8 @@ typedef struct swarm_hip_launch {
                                               per body (hermite, hermite_adap, mvs, rkck_*: small ensembles;
                                               irk2 from nbod 4 and rkck_* from nbod 9 on at every size; each
                                               with a no-op monitor or stop_on_ejection without printing,
-                                              hermite* also with log_time_interval; ignored elsewhere).
+                                              hermite* also with log_time_interval and the ejection-or-close-
+                                              encounter composite; ignored elsewhere).
                                               No reference key. */
     double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
                                               monitor's dt is time_step=                 */

@@ -551,17 +551,22 @@ __device__ __forceinline__ bool ej_test_quiet(const double (&p)[3], const double
     return fabs(epp) < 1e-4 || epp > 0;
 }
 
-// stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142
+// stop_on_close_encounter::check_close_encounters, monitors/stop_on_close_encounter.hpp:124-142, for one pair on
+// scalars: bodies i and j, the star's mass GM; `d` receives the separation
+__device__ __forceinline__ bool ce_test_quiet(const double (&pi)[3], const double (&pj)[3], const double mi,
+                                              const double mj, const double GM, const MonParams &mp, double &d) {
+#pragma clang fp contract(off)
+    const double dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
+    d = sqrt(dx * dx + dy * dy + dz * dz);
+    const double ri = sqrt(pi[0] * pi[0] + pi[1] * pi[1] + pi[2] * pi[2]);
+    const double a = 0.5 * (ri + ri); // the reference uses body i twice (L130)
+    const double rH3 = (mi + mj) / (3. * GM) * a * a * a;
+    return d * d * d < mp.dmin3 * rH3;
+}
 template <int N, bool VERBOSE>
 __device__ __forceinline__ bool ce_check(const State<N> &s, int i, int j, const MonParams &mp, const LogBuf &lg) {
-#pragma clang fp contract(off)
-    const double dx = s.p[i][0] - s.p[j][0], dy = s.p[i][1] - s.p[j][1], dz = s.p[i][2] - s.p[j][2];
-    const double d = sqrt(dx * dx + dy * dy + dz * dz);
-    const double GM = s.m[0];
-    const double ri = sqrt(s.p[i][0] * s.p[i][0] + s.p[i][1] * s.p[i][1] + s.p[i][2] * s.p[i][2]);
-    const double a = 0.5 * (ri + ri); // the reference uses body i twice (L130)
-    const double rH3 = (s.m[i] + s.m[j]) / (3. * GM) * a * a * a;
-    const bool close_encounter = d * d * d < mp.dmin3 * rH3;
+    double d;
+    const bool close_encounter = ce_test_quiet(s.p[i], s.p[j], s.m[i], s.m[j], s.m[0], mp, d);
     if (VERBOSE && close_encounter && mp.ce_verbose) // L137-141
         SWH_LPRINTF(lg, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", parg(s.number), parg(s.t),
                     parg(j), parg(i), parg(d));

@@ -220,12 +220,13 @@ static bool small_ensemble(const LaunchCtx &c) {
 }
 
 int launch_hermite(const LaunchCtx &c, bool adaptive) {
-    // small ensembles with nothing to monitor, with stop_on_ejection (deactivation and/or snapshot records, no printf)
-    // or with log_time_interval: one lane per body (kernels_hermite_body.hip), each lane testing its own planet and
+    // small ensembles with nothing to monitor, with stop_on_ejection or the ejection-or-close-encounter composite
+    // (deactivation and/or snapshot records, no printf) or with log_time_interval: one lane per body (kernels_hermite_body.hip), each lane testing its own planet and
     // writing its own body's part of a record
     const int variant = monitor_variant(c.mp);
     const bool body_ok = variant == MON_OFF || (variant == MON_ON && (c.mp.kind == SWARM_HIP_MON_EJECTION ||
-                                                                       c.mp.kind == SWARM_HIP_MON_LOG_INTERVAL));
+                                                                       c.mp.kind == SWARM_HIP_MON_LOG_INTERVAL ||
+                                                                       c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE));
     if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));

@@ -123,3 +123,43 @@ def test_log_overflow_in_the_lane_per_body_kernel(gpu, oracle):
     assert nbig == 200 * 25 and big[2] == 0
     assert 0 < nsmall == (64 << 10) // 288 and small[2] == nbig - nsmall      # what fits, and the rest counted
     assert set(split(small[1])) <= set(split(big[1]))
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("hermite_adap_close_encounter", {"time_step_factor": "0.017", "min_time_step": "1e-7"}),
+    ("hermite_cpu_ejection_or_close_encounter", {"time_step": "0.004"}),
+])
+@pytest.mark.parametrize("logged", [False, True])
+def test_ejection_or_close_encounter_composite(gpu, oracle, name, kw, logged):
+    """stop_on_ejection_or_close_encounter (composites.hpp:145-222) in the lane-per-body Hermite kernels: head-on
+    planets that meet at different times plus a few fast escapers; with and without log_on_* records.  States, stop
+    times, coordinates and records equal the lane-per-system kernel's; states equal the oracle's."""
+    from conftest import head_on
+    S, O = gpu, oracle
+    e = head_on(O, 128)
+    e.vel[5::9, 2] *= 1.6                               # some second planets leave instead: the ejection half
+    cfg = dict(kw, integrator=name, deactivate_on_close_encounter="1", close_approach="1.5",
+               deactivate_on_ejection="1", rmax="30")
+    if logged:
+        cfg.update(log_on_close_encounter="1", log_on_ejection="1")
+    out = {}
+    for mode in ("1", "2", "0"):
+        out[mode] = run_logged(S, e, dict(cfg, lane_mode=mode), 8.0)
+    (h1, raw1, _), (h2, raw2, _), (h0, raw0, _) = out["1"], out["2"], out["0"]
+    for k in FIELDS:
+        assert (getattr(h1, k) == getattr(h2, k)).all() and (getattr(h1, k) == getattr(h0, k)).all(), k
+    assert split(raw1) == split(raw2) == split(raw0)
+    gone = h2.state == O.DISABLED
+    assert 20 < gone.sum() < 128 and len(np.unique(h2.time[gone])) > 10
+    recs = O.parse_log(raw2)
+    if logged:
+        assert sorted({r["sys"] for r in recs}) == sorted(int(i) for i in h2.id[gone])
+    else:
+        assert recs == []
+    o = e.clone()
+    okw = dict(time_step_factor=0.017, min_time_step=1e-7) if "adap" in name else dict(time_step=0.004)
+    O.integrate(o, O.params("hermite_adap" if "adap" in name else "hermite_cpu", 8.0, **okw),
+                O.monitor(kind=O.MON_EJECTION_OR_CLOSE, rmax=30.0, deactivate_on_ejection=1, close_approach=1.5,
+                          deactivate_on_close_encounter=1, log_on_close_encounter=int(logged), log_on_ejection=int(logged)))
+    assert (h2.state == o.state).all()
+    np.testing.assert_allclose(h2.time, o.time, rtol=1e-9)
