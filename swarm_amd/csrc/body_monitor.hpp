@@ -1,0 +1,96 @@
+// body_monitor.hpp -- the monitors a lane-per-body kernel serves (kernels_*_body.hip), written once: stop_on_ejection
+// (stop_on_ejection.hpp:108-201), log_time_interval (log_time_interval.hpp:98-119) and the
+// ejection-or-close-encounter composite (composites.hpp:145-222, stop_on_close_encounter.hpp:101-142), each without
+// printing.  The N lanes of a system act as one monitor object: every lane tests its own planet (and, for close
+// encounters, the pairs (b, d), 1 <= d < b), ballots share the verdicts, every lane keeps the object's state
+// (next_log_time, the close-encounter flag) and the lanes write a snapshot record together (log_system_body).
+// The tests are the scalar helpers the lane-per-system monitors use (ej_test_quiet, ce_test_quiet), so outcomes,
+// stop steps and records are the lane-per-system kernels' (tests/test_gpu_body_logging.py).
+#pragma once
+#include "device_common.hpp"
+
+namespace swh {
+
+enum { MONB_NONE = -1, MONB_OFF = 0, MONB_EJECTION = 1, MONB_LOG_INTERVAL = 2, MONB_EJECTION_OR_CLOSE = 3 };
+
+// which of them a launch needs; MONB_NONE: a monitor only the lane-per-system kernels have (printing variants,
+// mce_stat, log_transit)
+inline int body_monitor_of(const MonParams &mp) {
+    const int variant = monitor_variant(mp);
+    if (variant == MON_OFF) return MONB_OFF;
+    if (variant != MON_ON) return MONB_NONE;
+    switch (mp.kind) {
+    case SWARM_HIP_MON_EJECTION: return MONB_EJECTION;
+    case SWARM_HIP_MON_LOG_INTERVAL: return MONB_LOG_INTERVAL;
+    case SWARM_HIP_MON_EJECTION_OR_CLOSE: return MONB_EJECTION_OR_CLOSE;
+    default: return MONB_NONE;
+    }
+}
+
+template <int N, int MONB>
+struct BodyMonitor {
+    double next_log_time; // log_time_interval.hpp:118-119
+    bool ce_met;          // stop_on_close_encounter's condition_met, kept between calls as the monitor object does
+
+    __device__ __forceinline__ void init(const double t) {
+        next_log_time = t;
+        ce_met = false;
+    }
+
+    // Monitor::operator() for the system whose body b this lane holds; called by the whole wavefront.
+    //   take_part     the system really calls its monitor now (the same in all lanes of a system)
+    //   star          lane of the system's body 0; group_mask: the lanes of the system
+    //   mass(d)       mass of body d of my system, asked for d < b only
+    //   convert(who, to_std)   for a propagator whose state is not in standard coordinates: the systems `who` go to
+    //                 standard coordinates for their record and back (generic_gpu_bppt_integrator.hpp:189-224)
+    template <class Mass, class Convert>
+    __device__ __forceinline__ void operator()(const bool take_part, const int b, const int star,
+                                               const unsigned long long group_mask, const double (&p)[3],
+                                               const double (&v)[3], const double m_own, Mass &&mass, const double t,
+                                               const int id, int &state, const MonParams &mp, const LogBuf &lg,
+                                               Convert &&convert) {
+        if (MONB == MONB_OFF) return;
+        bool want = false, ej_met = false;
+        if (MONB == MONB_EJECTION || MONB == MONB_EJECTION_OR_CLOSE) { // pass_one, stop_on_ejection.hpp:177-193
+            const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
+            ej_met = (__ballot(ej) & group_mask) != 0;
+            want = take_part && ej_met && mp.ej_log;
+        }
+        if (MONB == MONB_EJECTION_OR_CLOSE) {
+            // skipped for a system whose ejection is about to be logged: the composite's short-circuit ||
+            const bool ce_part = take_part && !want;
+            bool ce = false;
+            if (mp.ce_any) {
+#pragma unroll
+                for (int d = 1; d < N - 1; d++) {
+                    const double pj[3] = {__shfl(p[0], star + d), __shfl(p[1], star + d), __shfl(p[2], star + d)};
+                    double sep;
+                    const bool c = ce_test_quiet(p, pj, m_own, mass(d), mass(0), mp, sep);
+                    ce = ce || (d < b && c);
+                }
+            }
+            const bool ce_now = (__ballot(ce_part && ce) & group_mask) != 0;
+            if (ce_part) ce_met = ce_now;
+            want = take_part && ((mp.ej_log && ej_met) || (mp.ce_log && ce_met));
+        }
+        if (MONB == MONB_LOG_INTERVAL) { // log_time_interval.hpp:98-111
+#pragma clang fp contract(off)
+            want = take_part && mp.log_interval != 0. && t >= next_log_time;
+            if (want) next_log_time += mp.log_interval;
+        }
+        const bool logs = MONB == MONB_LOG_INTERVAL || mp.ej_log || (MONB == MONB_EJECTION_OR_CLOSE && mp.ce_log);
+        const bool any_rec = logs && __any(want);
+        if (any_rec) convert(want, true);
+        // pass_two: stop_on_ejection.hpp:196-201, stop_on_close_encounter.hpp:118-123
+        if (MONB != MONB_LOG_INTERVAL) {
+            if (take_part && ej_met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
+            if (MONB == MONB_EJECTION_OR_CLOSE && take_part && ce_met && mp.ce_deactivate) state = SWARM_HIP_DISABLED;
+        }
+        if (any_rec) {
+            log_system_body<N>(lg, want, b, star, t, id, state, p, v, m_own);
+            convert(want, false);
+        }
+    }
+};
+
+} // namespace swh

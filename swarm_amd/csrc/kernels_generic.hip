@@ -10,6 +10,7 @@
 //    block needs to log (syncthreads_or, L192); here only the system that asked is converted;
 //  * systems that are not ACTIVE at launch are left untouched (the reference runs MVS
 //    init()/shutdown() coordinate round trips on them, which perturbs their last bits).
+#include "body_monitor.hpp"
 #include "launch.hpp"
 #include "mvs_common.hpp"
 
@@ -441,8 +442,7 @@ int launch_generic(const LaunchCtx &c, int integrator) {
     switch (integrator) {
     case SWARM_HIP_MVS: {
         // small ensembles with nothing to monitor, or stop_on_ejection without printing
-        const int variant = monitor_variant(c.mp);
-        const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION);
+        const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
         if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_mvs_ensemble(c)))) return launch_mvs_body(c);
     }
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));

@@ -4,6 +4,7 @@
 // hermite_adap<Monitor,Grav>::kernel (integrators/hermite_adap.hpp:68-201) of the reference:
 // predictor, two force evaluations + correctors, time update, monitor and end-of-integration
 // test are one loop body over register-resident state; K steps per launch.
+#include "body_monitor.hpp"
 #include "launch.hpp"
 
 namespace swh {
@@ -223,10 +224,7 @@ int launch_hermite(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, with stop_on_ejection or the ejection-or-close-encounter composite
     // (deactivation and/or snapshot records, no printf) or with log_time_interval: one lane per body (kernels_hermite_body.hip), each lane testing its own planet and
     // writing its own body's part of a record
-    const int variant = monitor_variant(c.mp);
-    const bool body_ok = variant == MON_OFF || (variant == MON_ON && (c.mp.kind == SWARM_HIP_MON_EJECTION ||
-                                                                       c.mp.kind == SWARM_HIP_MON_LOG_INTERVAL ||
-                                                                       c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE));
+    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
     if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));

@@ -17,11 +17,10 @@
 // lanes of a system share the verdict through one ballot and, with log_on_ejection, write the snapshot record
 // together (log_system_body); for log_time_interval, MONB = 2 (log_time_interval.hpp:98-119), every lane keeping
 // its system's next_log_time; and for the ejection-or-close-encounter composite without printing, MONB = 3.
+#include "body_monitor.hpp"
 #include "launch.hpp"
 
 namespace swh {
-
-enum { MONB_OFF = 0, MONB_EJECTION = 1, MONB_LOG_INTERVAL = 2, MONB_EJECTION_OR_CLOSE = 3 };
 
 template <int N, int MONB, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
@@ -58,48 +57,12 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
         state = e.sysi[chunk * 2 * W + sl];
     }
     const int state_in = state;
-    // The monitor of one system, called by the whole wavefront.  stop_on_ejection: every lane tests its own planet,
-    // one ballot shares the verdict (pass_one), the state changes (pass_two), then the record (operator(), L140-146).
-    double next_log_time = t; // log_time_interval.hpp:118-119
-    bool ce_met = false;      // stop_on_close_encounter's condition_met, kept between calls as the monitor object does
+    // The monitor of one system, called by the whole wavefront (body_monitor.hpp)
+    BodyMonitor<N, MONB> monitor;
+    monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        bool want = false;
-        if (MONB == MONB_EJECTION_OR_CLOSE) {
-            // stop_on_ejection_or_close_encounter (composites.hpp:145-222), without printing: the ejection part as
-            // below; the close-encounter part -- skipped for a system whose ejection is about to be logged (the
-            // composite's short-circuit ||) -- with lane b testing the pairs (b, d), 1 <= d < b, of
-            // check_close_encounters (stop_on_close_encounter.hpp:101-142)
-            const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-            const bool ej_met = (__ballot(ej) & group_mask) != 0;
-            const bool ce_part = take_part && !(ej_met && mp.ej_log);
-            bool ce = false;
-            if (mp.ce_any) {
-#pragma unroll
-                for (int d = 1; d < N - 1; d++) {
-                    const double pj[3] = {__shfl(p[0], base + d), __shfl(p[1], base + d), __shfl(p[2], base + d)};
-                    double sep;
-                    const bool c = ce_test_quiet(p, pj, m_own, mo[d], mo[0], mp, sep);
-                    ce = ce || (d < b && c);
-                }
-            }
-            const bool ce_now = (__ballot(ce_part && ce) & group_mask) != 0;
-            if (ce_part) ce_met = ce_now;
-            if (take_part && ej_met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-            if (take_part && ce_met && mp.ce_deactivate) state = SWARM_HIP_DISABLED;
-            want = take_part && ((mp.ej_log && ej_met) || (mp.ce_log && ce_met));
-            if (!mp.ej_log && !mp.ce_log) return;
-        } else if (MONB == MONB_EJECTION) {
-            const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-            const bool met = (__ballot(ej) & group_mask) != 0;
-            if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-            want = take_part && met && mp.ej_log;
-            if (!mp.ej_log) return;
-        } else if (MONB == MONB_LOG_INTERVAL) {
-#pragma clang fp contract(off)
-            want = take_part && mp.log_interval != 0. && t >= next_log_time;
-            if (want) next_log_time += mp.log_interval;
-        }
-        log_system_body<N>(lg, want, b, base, t, id, state, p, v, m_own);
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+                [](bool, bool) {});
     };
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
     if (EJ && ADAPTIVE) ejection_monitor(valid);
@@ -231,10 +194,7 @@ template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-    const int monb = monitor_variant(c.mp) == MON_OFF                  ? MONB_OFF
-                     : c.mp.kind == SWARM_HIP_MON_LOG_INTERVAL         ? MONB_LOG_INTERVAL
-                     : c.mp.kind == SWARM_HIP_MON_EJECTION_OR_CLOSE    ? MONB_EJECTION_OR_CLOSE
-                                                                       : MONB_EJECTION;
+    const int monb = body_monitor_of(c.mp);
 #define SWH_LAUNCH_BODY(M, AD)                                                                                         \
     hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
     if (adaptive) {

@@ -14,6 +14,7 @@
 //
 // The reference binds the GPU plugin to mce_stat; as for `hermite` that monitor is used when the
 // ensemble carries >= 3 body attributes and stop_on_ejection (what irk2_cpu binds) otherwise.
+#include "body_monitor.hpp"
 #include "irk2_common.hpp"
 #include "mce_monitor.hpp"
 
@@ -222,8 +223,7 @@ int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
     if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
         if (int rc = mce_check_attributes(c)) return rc;
     // one lane per body (kernels_irk2_body.hip) with nothing to monitor, or stop_on_ejection without printing
-    const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT &&
-                         (monitor_is_noop(c.mp) || (monitor_variant(c.mp) == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION));
+    const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT && body_monitor_of(c.mp) != MONB_NONE;
     if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && irk2_prefers_body(c)))) return launch_irk2_body(c, method, cpu_rules);
     switch (method) {
     case 2: return launch_irk2_s2(c, cpu_rules);

@@ -17,16 +17,18 @@
 // lanes); a system that has converged, finished or given up computes and discards.
 // Serves the no-op monitor and stop_on_ejection without printing (deactivation, snapshot records); the one message of
 // the integrator itself, "no convergence of iteration", is printed by the star's lane.
+#include "body_monitor.hpp"
 #include "irk2_common.hpp"
 #include "launch.hpp"
 
 namespace swh {
 
-template <int N, int NS, bool EJ>
+template <int N, int NS, int MONB>
 __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt,
                                                        const double uround, const int nitmax, const bool cpu_rules) {
     using X = IrkCoord<NS>;
     constexpr int G = W / N; // systems per wavefront
+    constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     const long long sys_ll = (long long)blockIdx.x * G + g;
@@ -74,13 +76,12 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict; with
-    // log_on_ejection the lanes of the system write the snapshot record together (after the state change)
+    // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
+    BodyMonitor<N, MONB> monitor;
+    monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-        const bool met = (__ballot(ej) & group_mask) != 0;
-        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-        if (mp.ej_log) log_system_body<N>(lg, take_part && met, b, base, t, id, state, p, v, m_own);
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+                [](bool, bool) {});
     };
 
     unsigned long long steps = 0;
@@ -240,12 +241,16 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
     const int nitmax = cpu_rules ? 50 : 100;
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-    if (monitor_is_noop(c.mp))
-        hipLaunchKernelGGL((irk2_body_kernel<N, NS, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg,
-                           c.cnt, uround, nitmax, cpu_rules);
-    else
-        hipLaunchKernelGGL((irk2_body_kernel<N, NS, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg,
-                           c.cnt, uround, nitmax, cpu_rules);
+#define SWH_LAUNCH_BODY(M)                                                                                              \
+    hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt, \
+                       uround, nitmax, cpu_rules)
+    switch (body_monitor_of(c.mp)) {
+    case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
+    case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
+    case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;
+    default: SWH_LAUNCH_BODY(MONB_OFF); break;
+    }
+#undef SWH_LAUNCH_BODY
     return check_launch("irk2 (lane per body) kernel launch");
 }
 

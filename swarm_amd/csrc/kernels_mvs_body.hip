@@ -16,14 +16,16 @@
 // Used by launch_generic for the no-op monitor (MVS.cfg as shipped) and, EJ = true, for stop_on_ejection without
 // printing: every lane tests its own planet in the propagator's coordinates (generic_gpu_bppt_integrator.hpp:189-224
 // calls the monitor between init() and shutdown()); a system that logs is converted for the record and back.
+#include "body_monitor.hpp"
 #include "launch.hpp"
 #include "mvs_common.hpp"
 
 namespace swh {
 
-template <int N, bool EJ>
+template <int N, int MONB>
 __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
+    constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     const long long sys_ll = (long long)blockIdx.x * G + g;
@@ -166,20 +168,19 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             v[c] = planet ? nv[c] : v[c];
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict.  A system that
-    // is to be logged goes to standard coordinates for the record and back, as generic_mon_call does it
+    // The monitor of one system, called by the whole wavefront (body_monitor.hpp), in the propagator's coordinates; a
+    // system that is to be logged goes to standard coordinates for the record and back, as generic_mon_call does it
     // (generic_gpu_bppt_integrator.hpp:189-224: pass_one, conversion, pass_two, log, conversion back).
+    BodyMonitor<N, MONB> monitor;
+    monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-        const bool met = (__ballot(ej) & group_mask) != 0;
-        const bool rec = take_part && met && mp.ej_log;
-        const bool any_rec = mp.ej_log && __any(rec);
-        if (any_rec) to_std(rec);
-        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-        if (any_rec) {
-            log_system_body<N>(lg, rec, b, base, t, id, state, p, v, m_own);
-            to_internal(rec);
-        }
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return m[d]; }, t, id, state, mp, lg,
+                [&](const bool who, const bool std_coordinates) {
+                    if (std_coordinates)
+                        to_std(who);
+                    else
+                        to_internal(who);
+                });
     };
 
     if (__any(mine)) {
@@ -241,10 +242,15 @@ template <int N>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-    if (monitor_variant(c.mp) != MON_OFF)
-        hipLaunchKernelGGL((mvs_body_kernel<N, true>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt);
-    else
-        hipLaunchKernelGGL((mvs_body_kernel<N, false>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt);
+#define SWH_LAUNCH_BODY(M) \
+    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    switch (body_monitor_of(c.mp)) {
+    case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
+    case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
+    case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;
+    default: SWH_LAUNCH_BODY(MONB_OFF); break;
+    }
+#undef SWH_LAUNCH_BODY
     return check_launch("mvs (lane per body) kernel launch");
 }
 

@@ -12,6 +12,7 @@
 // last ACCEPTED step.
 #include <climits>
 
+#include "body_monitor.hpp"
 #include "launch.hpp"
 #include "rkck_common.hpp"
 
@@ -206,8 +207,7 @@ static bool small_rkck_ensemble(const LaunchCtx &c) {
 
 int launch_rkck(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, or stop_on_ejection without printing
-    const int variant = monitor_variant(c.mp);
-    const bool body_ok = variant == MON_OFF || (variant == MON_ON && c.mp.kind == SWARM_HIP_MON_EJECTION);
+    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
     if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_rkck_ensemble(c)))) return launch_rkck_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));

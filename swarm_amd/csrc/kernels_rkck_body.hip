@@ -14,14 +14,16 @@
 // forces for both; forces accumulate the partners in increasing index order and the two signs of a pair in acc_only
 // cancel), so both kernels give bit-identical ensembles, step sizes and accept/reject sequences
 // (tests/test_gpu_rkck_body.py).  Serves the no-op monitor and stop_on_ejection without printing (deactivation, snapshot records).
+#include "body_monitor.hpp"
 #include "launch.hpp"
 #include "rkck_common.hpp"
 
 namespace swh {
 
-template <int N, bool ADAPTIVE, bool EJ>
+template <int N, bool ADAPTIVE, int MONB>
 __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
+    constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     const long long sys_ll = (long long)blockIdx.x * G + g;
@@ -69,13 +71,12 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
     };
-    // stop_on_ejection of one system: every lane tests its own planet, one ballot shares the verdict; with
-    // log_on_ejection the lanes of the system write the snapshot record together (after the state change, L140-146)
+    // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
+    BodyMonitor<N, MONB> monitor;
+    monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);
-        const bool met = (__ballot(ej) & group_mask) != 0;
-        if (take_part && met && mp.ej_deactivate) state = SWARM_HIP_DISABLED;
-        if (mp.ej_log) log_system_body<N>(lg, take_part && met, b, base, t, id, state, p, v, m_own);
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+                [](bool, bool) {});
     };
     if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
 
@@ -159,20 +160,22 @@ template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
     const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
-    const bool ej = monitor_variant(c.mp) != MON_OFF;
-#define SWH_LAUNCH_BODY(AD, EJ) \
-    hipLaunchKernelGGL((rkck_body_kernel<N, AD, EJ>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
-    if (adaptive) {
-        if (ej)
-            SWH_LAUNCH_BODY(true, true);
-        else
-            SWH_LAUNCH_BODY(true, false);
-    } else {
-        if (ej)
-            SWH_LAUNCH_BODY(false, true);
-        else
-            SWH_LAUNCH_BODY(false, false);
+    const int monb = body_monitor_of(c.mp);
+#define SWH_LAUNCH_BODY(AD, M) \
+    hipLaunchKernelGGL((rkck_body_kernel<N, AD, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+#define SWH_LAUNCH_BODY_MON(AD)                                       \
+    switch (monb) {                                                   \
+    case MONB_EJECTION: SWH_LAUNCH_BODY(AD, MONB_EJECTION); break;    \
+    case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(AD, MONB_EJECTION_OR_CLOSE); break; \
+    case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(AD, MONB_LOG_INTERVAL); break; \
+    default: SWH_LAUNCH_BODY(AD, MONB_OFF); break;                    \
     }
+    if (adaptive) {
+        SWH_LAUNCH_BODY_MON(true)
+    } else {
+        SWH_LAUNCH_BODY_MON(false)
+    }
+#undef SWH_LAUNCH_BODY_MON
 #undef SWH_LAUNCH_BODY
     return check_launch("rkck (lane per body) kernel launch");
 }

@@ -125,19 +125,28 @@ def test_log_overflow_in_the_lane_per_body_kernel(gpu, oracle):
     assert set(split(small[1])) <= set(split(big[1]))
 
 
-@pytest.mark.parametrize("name,kw", [
-    ("hermite_adap_close_encounter", {"time_step_factor": "0.017", "min_time_step": "1e-7"}),
-    ("hermite_cpu_ejection_or_close_encounter", {"time_step": "0.004"}),
-])
+COMPOSITE = {
+    # plugin: (cfg, oracle integrator, oracle params)
+    "hermite_adap_close_encounter": ({"time_step_factor": "0.017", "min_time_step": "1e-7"}, "hermite_adap",
+                                     dict(time_step_factor=0.017, min_time_step=1e-7)),
+    "hermite_cpu_ejection_or_close_encounter": ({"time_step": "0.004"}, "hermite_cpu", dict(time_step=0.004)),
+    "rkck_adaptive_close_encounter": ({"min_time_step": "1e-6", "max_time_step": "0.02", "error_tolerance": "1e-20"},
+                                      "rkck_adaptive", dict(min_time_step=1e-6, max_time_step=0.02, error_tolerance=1e-20)),
+    "mvs_close_encounter": ({"time_step": "0.004"}, "mvs", dict(time_step=0.004)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(COMPOSITE))
 @pytest.mark.parametrize("logged", [False, True])
-def test_ejection_or_close_encounter_composite(gpu, oracle, name, kw, logged):
-    """stop_on_ejection_or_close_encounter (composites.hpp:145-222) in the lane-per-body Hermite kernels: head-on
+def test_ejection_or_close_encounter_composite(gpu, oracle, name, logged):
+    """stop_on_ejection_or_close_encounter (composites.hpp:145-222) in the lane-per-body kernels: head-on
     planets that meet at different times plus a few fast escapers; with and without log_on_* records.  States, stop
     times, coordinates and records equal the lane-per-system kernel's; states equal the oracle's."""
     from conftest import head_on
     S, O = gpu, oracle
     e = head_on(O, 128)
     e.vel[5::9, 2] *= 1.6                               # some second planets leave instead: the ejection half
+    kw, oname, okw = COMPOSITE[name]
     cfg = dict(kw, integrator=name, deactivate_on_close_encounter="1", close_approach="1.5",
                deactivate_on_ejection="1", rmax="30")
     if logged:
@@ -157,9 +166,33 @@ def test_ejection_or_close_encounter_composite(gpu, oracle, name, kw, logged):
     else:
         assert recs == []
     o = e.clone()
-    okw = dict(time_step_factor=0.017, min_time_step=1e-7) if "adap" in name else dict(time_step=0.004)
-    O.integrate(o, O.params("hermite_adap" if "adap" in name else "hermite_cpu", 8.0, **okw),
+    O.integrate(o, O.params(oname, 8.0, **okw),
                 O.monitor(kind=O.MON_EJECTION_OR_CLOSE, rmax=30.0, deactivate_on_ejection=1, close_approach=1.5,
                           deactivate_on_close_encounter=1, log_on_close_encounter=int(logged), log_on_ejection=int(logged)))
     assert (h2.state == o.state).all()
-    np.testing.assert_allclose(h2.time, o.time, rtol=1e-9)
+    if not name.startswith("rkck"):                     # rkck's step sizes come through pow(): stop times to a step
+        np.testing.assert_allclose(h2.time, o.time, rtol=1e-9)
+
+
+@pytest.mark.parametrize("which", ["MVS", "RKCK_ADAPTIVE", "IRK2"])
+def test_log_time_interval_with_the_other_integrators(gpu, oracle, which, monkeypatch):
+    """The C-ABI takes any (integrator, monitor) pair; the reference registers log_time_interval with the Hermite
+    integrators only.  Through the ABI (a plugin entry added for the test) the lane-per-body MVS, Cash-Karp and Gauss
+    IRK kernels log like the lane-per-system ones: same records, same ensembles -- MVS converting the system that
+    logs to standard coordinates and back each time."""
+    S, O = gpu, oracle
+    import swarm_amd.integrator as I
+    monkeypatch.setitem(I.PLUGINS, "integrator_log_test", (getattr(S.capi, which), S.capi.MON_LOG_INTERVAL))
+    cfg = {"MVS": {"time_step": "0.004"},
+           "RKCK_ADAPTIVE": {"min_time_step": "1e-6", "max_time_step": "0.01", "error_tolerance": "1e-20"},
+           "IRK2": {"time_step": "0.02"}}[which]
+    e = perturbed(O, 150, 5, seed=41)
+    e.time[:] = np.linspace(0.0, 0.05, 150)
+    out = {}
+    for mode in ("1", "2"):
+        out[mode] = run_logged(S, e, dict(cfg, integrator="log_test", log_interval="0.0503", lane_mode=mode), 0.6)
+    (h1, raw1, _), (h2, raw2, _) = out["1"], out["2"]
+    for k in FIELDS:
+        assert (getattr(h1, k) == getattr(h2, k)).all(), k
+    r1, r2 = split(raw1), split(raw2)
+    assert r1 == r2 and len(r2) >= 150 * 10
