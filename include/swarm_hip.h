@@ -127,10 +127,9 @@ typedef struct swarm_hip_launch {
     int32_t lane_mode;                     /* 0 = choose by nbod and nsys; 1 = one lane per system; 2 = one lane
                                               per body (hermite, hermite_adap, mvs, rkck_*: small ensembles;
                                               irk2 from nbod 4 and rkck_* from nbod 9 on at every size; each
-                                              with a no-op monitor or stop_on_ejection without printing,
-                                              hermite* also with log_time_interval and the ejection-or-close-
-                                              encounter composite; ignored elsewhere).
-                                              No reference key. */
+                                              with a no-op monitor, stop_on_ejection, log_time_interval or the
+                                              ejection-or-close-encounter composite without printing; ignored
+                                              elsewhere).  No reference key. */
     double log_transit_tol;                /* log_transit_tol= (default 2e-8; 0 = off); the
                                               monitor's dt is time_step=                 */
     int32_t kepler_compensated;            /* kepler_compensated= (mvs; default 0; no reference key).  0: the f and g
