@@ -223,6 +223,27 @@ __device__ __forceinline__ void acc_only(const double (&p)[N][3], const double (
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lane-per-body kernels (one wavefront per workgroup): K doubles per lane handed to the other lanes of the wavefront
+// through LDS -- one or two wide stores per lane and K/2 16-byte loads per partner instead of 2 K ds_bpermute_b32.
+// The exchange is what bounds those kernels at saturation (irk2, 65536 x 6: 8.29 -> 7.75 ms; 2048 x 6: 1.135 -> 1.085).
+// `slot` is a __shared__ array of W rows declared by the kernel; put() ... get() ... done() bracket one exchange.
+template <int K>
+struct LaneExchange {
+    static constexpr int KP = (K + 1) / 2 * 2; // rows padded to 16 bytes
+    typedef double Row[KP];
+    static __device__ __forceinline__ void put(Row *slot, const int lane, const double (&x)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; k++) slot[lane][k] = x[k];
+        __syncthreads(); // a single wavefront: orders the stores before the loads, no waiting
+    }
+    static __device__ __forceinline__ void get(const Row *slot, const int src, double (&x)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; k++) x[k] = slot[src][k];
+    }
+    static __device__ __forceinline__ void done() { __syncthreads(); } // loads before the next put()
+};
+
+// ---------------------------------------------------------------------------------------------
 // Per-step constants that depend only on h.  For the fixed-step integrator h changes at most once
 // per launch (the clipped last step), so they are recomputed only when h changes.
 struct StepConsts {

@@ -431,10 +431,10 @@ static int launch_n(const LaunchCtx &c) {
 
 // One lane per body pays while the ensemble is too small to fill the chip with wavefronts of whole systems
 // (kernels_mvs_body.hip).  Crossovers measured with WORKLOAD=c4 tools/lane_sweep.sh (profiles/r2/mvs_lane_sweep.txt):
-// nsys ~ 8k for nbod 3, 32k for nbod 4, 24-32k for nbod 5..10; below 4096 systems the lane-per-body kernel is 1.5x
-// (nbod 4) to 3.6x (nbod 10) faster.  Limits sit at the last grid point where it still wins.
+// nsys ~ 8k for nbod 3, 24-36k for nbod 4..10; at 4096 systems the lane-per-body kernel is 1.5x (nbod 4) to 3.9x
+// (nbod 10) faster.  Limits sit at the last grid point where it still wins.
 static bool small_mvs_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 32768, 24576, 24576, 24576, 24576, 20480, 24576};
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 20480, 24576, 24576, 24576, 32768, 24576, 24576};
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
 }
 

@@ -213,10 +213,11 @@ static int launch_n(const LaunchCtx &c) {
 }
 
 // One lane per body pays while the ensemble is too small to give every SIMD a wavefront of whole systems;
-// beyond the measured crossover (tools/lane_sweep.sh, DESIGN 5: nsys ~ 8k for nbod 3, 16-24k for nbod 4..9,
-// 33k for nbod 10) the lane-per-system kernel's throughput wins.  Limits sit a little below the crossovers.
+// beyond the measured crossover (tools/lane_sweep.sh, profiles/r2/hermite_lane_sweep.txt, DESIGN 5: nsys ~ 22k for
+// nbod 3..7 and 9, 36k for nbod 8, 45k for nbod 10) the lane-per-system kernel's throughput wins.  Limits sit at the
+// last grid point where the lane-per-body kernel still wins.
 static bool small_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 16384, 12288, 16384, 16384, 20480, 16384, 28672};
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 20480, 24576, 24576, 24576, 32768, 24576, 40960};
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
 }
 

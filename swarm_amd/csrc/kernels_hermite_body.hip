@@ -67,13 +67,21 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
     if (EJ && ADAPTIVE) ejection_monitor(valid);
 
-    // forces on my body from the current p, v of all lanes; wave-wide (shuffles), no divergence inside
+    // forces on my body from the current p, v of all lanes; wave-wide, no divergence inside; positions and velocities
+    // travel through LDS (LaneExchange, device_common.hpp)
+    typedef LaneExchange<6> Xchg;
+    __shared__ __align__(16) typename Xchg::Row xchg[W];
     auto forces = [&](double (&a)[3], double (&jk)[3]) {
+        {
+            const double pv6[6] = {p[0], p[1], p[2], v[0], v[1], v[2]};
+            Xchg::put(xchg, lane, pv6);
+        }
 #pragma unroll
         for (int q = 0; q < N - 1; q++) {
-            const int src = base + (q < b ? q : q + 1);
-            const double d0 = __shfl(p[0], src) - p[0], d1 = __shfl(p[1], src) - p[1], d2 = __shfl(p[2], src) - p[2];
-            const double e0 = __shfl(v[0], src) - v[0], e1 = __shfl(v[1], src) - v[1], e2 = __shfl(v[2], src) - v[2];
+            double o[6];
+            Xchg::get(xchg, (base + (q < b ? q : q + 1)) & (W - 1), o);
+            const double d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
+            const double e0 = o[3] - v[0], e1 = o[4] - v[1], e2 = o[5] - v[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double xv = __builtin_fma(d2, e2, __builtin_fma(d1, e1, d0 * e0));
             const double y = rsqrt_full(r2);
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
                 jk[2] = __builtin_fma(t2, sc, jk[2]);
             }
         }
+        Xchg::done();
     };
 
     unsigned long long steps = 0;

@@ -214,7 +214,7 @@ int SWH_IRK2_CAT(launch_irk2_s, SWH_IRK2_NS)(const LaunchCtx &c, bool cpu_rules)
 
 #if SWH_IRK2_NS == 2
 // From nbod 4 on the lane-per-system kernel is bound by scratch traffic and the lane-per-body kernel wins at every
-// ensemble size (65536 systems: 3x at nbod 4 ... 4.5x at nbod 10; 2048 systems: 7x ... 18x); at nbod 3 it wins while
+// ensemble size (65536 systems: 3x at nbod 4 ... 5x at nbod 10; 2048 systems: 7x ... 20x); at nbod 3 it wins while
 // the ensemble is too small to fill the chip with wavefronts of whole systems (crossover ~ 55k systems).
 // WORKLOAD=irk2 tools/lane_sweep.sh, profiles/r2/irk2_lane_sweep.txt.
 static bool irk2_prefers_body(const LaunchCtx &c) { return c.ens.nbod >= 4 || c.ens.nsys <= 49152; }

@@ -59,14 +59,18 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
     }
     const int state_in = state;
 
-    // the force on my body with all bodies at `pos` (acc_only<N, false>); wave-wide, no divergence inside
+    // the force on my body with all bodies at `pos` (acc_only<N, false>); wave-wide, no divergence inside; the
+    // positions travel through LDS (LaneExchange, device_common.hpp)
+    typedef LaneExchange<3> Xchg;
+    __shared__ __align__(16) typename Xchg::Row xchg[W];
     auto force = [&](const double (&pos)[3], double (&a)[3]) {
+        Xchg::put(xchg, lane, pos);
         a[0] = a[1] = a[2] = 0.0;
 #pragma unroll
         for (int q = 0; q < N - 1; q++) {
-            const int src = base + (q < b ? q : q + 1);
-            const double d0 = __shfl(pos[0], src) - pos[0], d1 = __shfl(pos[1], src) - pos[1],
-                         d2 = __shfl(pos[2], src) - pos[2];
+            double pj[3];
+            Xchg::get(xchg, base + (q < b ? q : q + 1), pj);
+            const double d0 = pj[0] - pos[0], d1 = pj[1] - pos[1], d2 = pj[2] - pos[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double y = rsqrt_full(r2);
             const double rinv = y * (y * y);
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
             a[1] = __builtin_fma(d1, sc, a[1]);
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
+        Xchg::done();
     };
     // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
     BodyMonitor<N, MONB> monitor;

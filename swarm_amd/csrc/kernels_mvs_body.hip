@@ -109,25 +109,37 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             }
         }
     };
-    // MVSPropagator::drift_step, mvs.hpp:242-256 (mvs_drift)
+    // MVSPropagator::drift_step, mvs.hpp:242-256 (mvs_drift); the planets' velocities travel through LDS
+    typedef LaneExchange<3> Xchg;
+    __shared__ __align__(16) typename Xchg::Row xchg[W];
     auto drift = [&](const double hby2, const double inv_m0) {
 #pragma clang fp contract(off)
+        Xchg::put(xchg, lane, v);
+        double mv[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            double vj[3];
+            Xchg::get(xchg, base + j, vj);
+#pragma unroll
+            for (int c = 0; c < 3; c++) mv[c] = __builtin_fma(m[j], vj[c], mv[c]);
+        }
+        Xchg::done();
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            double mv = 0;
-#pragma unroll
-            for (int j = 1; j < N; ++j) mv = __builtin_fma(m[j], __shfl(v[c], base + j), mv);
-            const double shift = (mv * hby2) * inv_m0;
+            const double shift = (mv[c] * hby2) * inv_m0;
             p[c] = b == 0 ? __builtin_fma(hby2, v[c], p[c]) : p[c] + shift;
         }
     };
-    // GravitationAcc::sum_acc_planets (gravitation_acc.hpp:96-139) for my planet; acc_only<N, true>
+    // GravitationAcc::sum_acc_planets (gravitation_acc.hpp:96-139) for my planet; acc_only<N, true>; the positions
+    // travel through LDS (LaneExchange, device_common.hpp)
     auto planet_forces = [&](double (&a)[3]) {
+        Xchg::put(xchg, lane, p);
         a[0] = a[1] = a[2] = 0.0;
 #pragma unroll
         for (int q = 0; q < N - 2; q++) {
-            const int src = base + ((q + 1 < b) ? q + 1 : q + 2); // fellow planets in increasing index order
-            const double d0 = __shfl(p[0], src) - p[0], d1 = __shfl(p[1], src) - p[1], d2 = __shfl(p[2], src) - p[2];
+            double pj[3];
+            Xchg::get(xchg, base + ((q + 1 < b) ? q + 1 : q + 2), pj); // fellow planets in increasing index order
+            const double d0 = pj[0] - p[0], d1 = pj[1] - p[1], d2 = pj[2] - p[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double y = rsqrt_full(r2);
             const double rinv = y * (y * y);
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             a[1] = __builtin_fma(d1, sc, a[1]);
             a[2] = __builtin_fma(d2, sc, a[2]);
         }
+        Xchg::done();
         if (!planet) a[0] = a[1] = a[2] = 0.0; // the star is not kicked
     };
     // drift_kepler of my planet (the star's and idle lanes go through the same instructions and discard)

@@ -197,11 +197,11 @@ static int launch_n(const LaunchCtx &c) {
 
 // One lane per body (kernels_rkck_body.hip) pays while the ensemble is too small to fill the chip with wavefronts of
 // whole systems, and at nbod 9 and 10 -- where the six stage accelerations of all bodies spill to scratch with one lane
-// per system -- at every size (65536 systems: 156 -> 69 ms and 196 -> 86 ms per 200 attempts).  Crossovers measured
-// with WORKLOAD=c3 tools/lane_sweep.sh (profiles/r2/rkck_lane_sweep.txt); below 8192 systems the lane-per-body kernel
-// is 1.2x (nbod 3) to 13x (nbod 10) faster.
+// per system -- at every size (65536 systems: 156 -> 57 ms and 196 -> 68 ms per 200 attempts).  Crossovers measured
+// with WORKLOAD=c3 tools/lane_sweep.sh (profiles/r2/rkck_lane_sweep.txt); at 2048 systems the lane-per-body kernel
+// is 1.2x (nbod 3) to 15x (nbod 10) faster.
 static bool small_rkck_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 20480, 24576, 20480, 32768, 40960, INT_MAX, INT_MAX};
+    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 32768, 24576, 20480, 40960, 49152, INT_MAX, INT_MAX};
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
 }
 
