@@ -5,7 +5,7 @@
 // is (the reference's saturation sweep, scripts/saturation: nsys = 32 ... 32768, is flat).  Here the
 // nbod bodies of a system sit in nbod adjacent lanes (floor(64/nbod) systems per wavefront): a lane
 // predicts and corrects its own body and sums the forces of its nbod-1 partners, whose predicted
-// positions and velocities it reads from the partner lanes (ds_bpermute).  The dependent chain per
+// positions and velocities it reads from the partner lanes (rows in LDS, LaneExchange).  The dependent chain per
 // step is about nbod/2.5 times shorter, at the price of computing every pair on both sides.
 //
 // Arithmetic is that of accjerk<N> / hermite_step<N> (device_common.hpp) operation for operation:
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     k.set(ip.time_step);
     int iter = 0;
     bool active = valid && state == SWARM_HIP_ACTIVE && iter < ip.max_iterations;
-    // Every lane walks through every step of the slowest system of its wave (the shuffles need all lanes);
+    // Every lane walks through every step of the slowest system of its wave (the exchange needs all lanes);
     // lanes of finished or idle groups compute and discard.
     while (__any(active)) {
         double h = ip.time_step;

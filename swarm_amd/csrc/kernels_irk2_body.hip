@@ -5,7 +5,7 @@
 // lane -- 216 at nbod 6, s = 6 -- and from nbod 4 on they do not fit the register file next to the state: the kernel
 // is bound by scratch traffic.  Here the nbod bodies of a system sit in nbod adjacent lanes (floor(64/nbod) systems per
 // wavefront, one wavefront per workgroup): a lane keeps F and ZQ of its own body only (36 doubles at s = 6), evaluates
-// the force on its body at every stage from its partners' stage positions (ds_bpermute) and runs the method's
+// the force on its body at every stage from its partners' stage positions (rows in LDS, LaneExchange) and runs the method's
 // per-coordinate arithmetic on its three coordinates.  The reference's own kernel is laid out the same way one level
 // finer (3 nbod threads per system, L83-107); as there, the convergence norm is the one quantity the lanes of a system
 // add up together (L212-227: shared memory and two barriers; here nbod shuffles, every lane forming the same sum).

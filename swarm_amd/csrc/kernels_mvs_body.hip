@@ -6,7 +6,7 @@
 // is the Kepler solver of one planet after the other.  Here the nbod bodies of a system sit in nbod adjacent lanes
 // (floor(64/nbod) systems per wavefront, one wavefront per workgroup): every planet's lane solves its own Kepler
 // problem, all at once, and sums the accelerations of its nbod-2 fellow planets, whose positions it reads from the
-// partner lanes (ds_bpermute); the star's lane carries the barycentre and otherwise rides along.  The sums over all
+// partner lanes (rows in LDS, LaneExchange); the star's lane carries the barycentre and otherwise rides along.  The sums over all
 // bodies of a system (coordinate changes, the star's drift) are formed by every lane of the system, in index order.
 //
 // Arithmetic is that of the lane-per-system kernel operation for operation: mvs_common.hpp holds the solver for both,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
         // prop.init()
         to_internal(mine);
         planet_forces(acc);
-        // Every lane walks through every step of the slowest system of its wave (the shuffles need all lanes); the
+        // Every lane walks through every step of the slowest system of its wave (the exchange needs all lanes); the
         // lanes of a finished or idle system take steps of h = 0, which leave their registers as they are.
         for (int iter = 0; iter < ip.max_iterations && __any(live); iter++) {
             double max_timestep;

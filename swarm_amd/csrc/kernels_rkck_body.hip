@@ -5,7 +5,7 @@
 // six stage accelerations of all bodies (108 doubles at nbod 6) go through AGPRs; below one wavefront per SIMD the
 // run time is that chain's latency whatever nsys is.  Here the nbod bodies of a system sit in nbod adjacent lanes
 // (floor(64/nbod) systems per wavefront, one wavefront per workgroup): a lane keeps the 18 stage accelerations of its
-// own body, evaluates the force on it from its partners' stage positions (ds_bpermute) and forms its own stage
+// own body, evaluates the force on it from its partners' stage positions (rows in LDS, LaneExchange) and forms its own stage
 // positions, solution and error estimate; the system's normalised error is the maximum over its lanes, and every lane
 // of a system runs the same step control on it.  The reference's kernel is laid out the same way one level finer
 // (3 nbod threads per system, L90-131).
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     double time_step = ip.max_time_step; // L133
     unsigned long long accepted = 0, attempted = 0;
 
-    // Every lane goes through every attempt of the slowest system of its wave (the shuffles need all lanes); a system
+    // Every lane goes through every attempt of the slowest system of its wave (the exchange needs all lanes); a system
     // that is done, or was not ACTIVE at launch, never commits.
     bool live = valid && state == SWARM_HIP_ACTIVE;
     for (int iter = 0; iter < iteration_count && __any(live); iter++) {
