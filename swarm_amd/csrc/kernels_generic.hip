@@ -13,6 +13,7 @@
 #include "body_monitor.hpp"
 #include "launch.hpp"
 #include "mvs_common.hpp"
+#include "propagators_common.hpp"
 
 namespace swh {
 
@@ -286,17 +287,12 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 s.t += h;
             } else if (KIND == SWARM_HIP_EULER) { // EulerPropagator::advance, euler.hpp:101-122
                 const double h = (!WHOLE || live) ? fmin(ip.time_step, max_timestep) : 0.0;
-                const double third = 1.0 / 3.0;
                 double jerk[N][3];
                 accjerk<N>(s.p, s.v, s.m, acc, jerk);
 #pragma unroll
                 for (int b = 0; b < N; b++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const double pos = s.p[b][c], vel = s.v[b][c];
-                        s.p[b][c] = pos + h * (vel + (h * 0.5) * (acc[b][c] + (h * third) * jerk[b][c]));
-                        s.v[b][c] = vel + h * (acc[b][c] + (h * 0.5) * jerk[b][c]);
-                    }
+                    for (int c = 0; c < 3; c++) euler_advance(h, acc[b][c], jerk[b][c], s.p[b][c], s.v[b][c]);
                 s.t += h;
             } else if (KIND == SWARM_HIP_VERLET) { // VerletPropagator::advance, verlet.hpp:139-175
                 const double h = (!WHOLE || live) ? timestep : 0.0;
@@ -332,8 +328,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 for (int b = 0; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        p_i[b][c] = p_im1[b][c] + h * v_im1[b][c];
-                        v_i[b][c] = v_im1[b][c] + h * acc[b][c];
+                        midpoint_first(h, p_im1[b][c], v_im1[b][c], acc[b][c], p_i[b][c], v_i[b][c]);
                     }
 #pragma unroll
                 for (int i = 2; i <= n; i++) {
@@ -349,8 +344,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                     for (int b = 0; b < N; b++)
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-                            p_i[b][c] = p_im2[b][c] + 2.0 * h * v_im1[b][c];
-                            v_i[b][c] = v_im2[b][c] + 2.0 * h * acc[b][c];
+                            midpoint_next(h, p_im2[b][c], v_im2[b][c], v_im1[b][c], acc[b][c], p_i[b][c], v_i[b][c]);
                         }
                 }
                 acc_only<N, false>(p_i, s.m, acc);
@@ -358,8 +352,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 for (int b = 0; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        s.p[b][c] = 0.5 * (p_i[b][c] + p_im1[b][c] + h * v_i[b][c]);
-                        s.v[b][c] = 0.5 * (v_i[b][c] + v_im1[b][c] + h * acc[b][c]);
+                        midpoint_last(h, p_i[b][c], p_im1[b][c], v_i[b][c], v_im1[b][c], acc[b][c], s.p[b][c], s.v[b][c]);
                     }
                 s.t += H;
             }
@@ -438,6 +431,18 @@ static bool small_mvs_ensemble(const LaunchCtx &c) {
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
 }
 
+// euler, midpoint, hermite_prop: one lane per body (kernels_prop_body.hip) for small ensembles.  Measured crossovers
+// (profiles/r2/prop_lane_sweep.txt): the lane-per-system kernels take the same time from 2048 to 65536 systems (one
+// wavefront per SIMD at most), the lane-per-body kernels win below ~16384 systems from nbod 6 on (nbod 10, 2048
+// systems: 4x), and at nbod 3 only hermite_prop gains anything.
+static bool prop_body_selected(const LaunchCtx &c, int integrator) {
+    if (body_monitor_of(c.mp) == MONB_NONE) return false;
+    if (c.lane_mode != 0) return c.lane_mode == 2;
+    const int nbod = c.ens.nbod;
+    if (nbod == 3) return integrator == SWARM_HIP_HERMITE_PROP && c.ens.nsys <= 8192;
+    return c.ens.nsys <= (nbod < 6 ? 8192 : 16384);
+}
+
 int launch_generic(const LaunchCtx &c, int integrator) {
     switch (integrator) {
     case SWARM_HIP_MVS: {
@@ -448,15 +453,18 @@ int launch_generic(const LaunchCtx &c, int integrator) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
         break;
     case SWARM_HIP_EULER:
+        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_EULER>(c)));
         break;
     case SWARM_HIP_VERLET:
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_VERLET>(c)));
         break;
     case SWARM_HIP_MIDPOINT:
+        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MIDPOINT>(c)));
         break;
     case SWARM_HIP_HERMITE_PROP:
+        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_HERMITE_PROP>(c)));
         break;
     default:

@@ -1,0 +1,253 @@
+// kernels_prop_body.hip -- the tutorial propagators euler (third-order Taylor), midpoint (modified midpoint, 4 substeps)
+// and hermite_prop (PEC2 Hermite as a propagator) of generic<Propagator,Monitor,Gravitation>::kernel
+// (swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238, propagators/{euler,midpoint,hermite_propagator}.hpp) with ONE
+// LANE PER BODY, for small ensembles -- the layout of kernels_hermite_body.hip: floor(64/nbod) systems per wavefront,
+// one wavefront per workgroup, a lane advances its own body and sums the forces of its partners, whose positions
+// (and velocities) it reads from rows in LDS (LaneExchange).
+//
+// Arithmetic is that of the lane-per-system kernel (kernels_generic.hip) operation for operation: forces as
+// accjerk<N> / acc_only<N, false> accumulate them per body, the per-coordinate updates from propagators_common.hpp
+// and hermite_step<N>; both kernels give bit-identical ensembles (tests/test_gpu_prop_body.py).  Monitors:
+// body_monitor.hpp.  (verlet stays one lane per system: its time step is one sum over all ordered pairs of a system.)
+#include "body_monitor.hpp"
+#include "launch.hpp"
+#include "propagators_common.hpp"
+
+namespace swh {
+
+template <int N, int KIND, int MONB>
+__global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
+    constexpr int G = W / N; // systems per wavefront
+    constexpr bool EJ = MONB != MONB_OFF;
+    constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
+    const int lane = threadIdx.x;
+    const int g = lane / N, b = lane - g * N;
+    const long long sys_ll = (long long)blockIdx.x * G + g;
+    const bool valid = lane < G * N && sys_ll < e.nsys;
+    const int sys = valid ? (int)sys_ll : 0;
+    const int base = valid ? g * N : 0; // first lane of my system (idle lanes read system 0 of the wave)
+    const unsigned long long group_mask = ((1ull << N) - 1) << base;
+
+    const size_t chunk = sys / W, sl = sys % W;
+    double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
+    double p[3], v[3], mo[N - 1], t = 0.0;
+    int state = SWARM_HIP_DISABLED;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
+        v[c] = valid ? row[(3 + c) * W] : 0.0;
+    }
+    const double m_own = valid ? row[6 * W] : 1.0;
+    const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
+#pragma unroll
+    for (int q = 0; q < N - 1; q++) {
+        const int j = q < b ? q : q + 1; // partners in increasing index order
+        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+    }
+    if (valid) {
+        t = e.sysd[chunk * e.nsf * W + sl];
+        state = e.sysi[chunk * 2 * W + sl];
+    }
+
+    typedef LaneExchange<6> Xchg6;
+    typedef LaneExchange<3> Xchg3;
+    __shared__ __align__(16) typename Xchg6::Row xchg6[W];
+    __shared__ __align__(16) typename Xchg3::Row xchg3[W];
+    // acceleration and jerk of my body from (pos, vel) of all lanes: accjerk<N>, first term by multiplication
+    auto accjerk_body = [&](const double (&pos)[3], const double (&vel)[3], double (&a)[3], double (&jk)[3]) {
+        {
+            const double pv6[6] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2]};
+            Xchg6::put(xchg6, lane, pv6);
+        }
+#pragma unroll
+        for (int q = 0; q < N - 1; q++) {
+            double o[6];
+            Xchg6::get(xchg6, base + (q < b ? q : q + 1), o);
+            const double d0 = o[0] - pos[0], d1 = o[1] - pos[1], d2 = o[2] - pos[2];
+            const double e0 = o[3] - vel[0], e1 = o[4] - vel[1], e2 = o[5] - vel[2];
+            const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+            const double xv = __builtin_fma(d2, e2, __builtin_fma(d1, e1, d0 * e0));
+            const double y = rsqrt_full(r2);
+            const double y2 = y * y;
+            const double rinv = y * y2;
+            const double rv = (xv * 3.0) * y2;
+            const double sc = rinv * mo[q];
+            const double t0 = __builtin_fma(-d0, rv, e0), t1 = __builtin_fma(-d1, rv, e1), t2 = __builtin_fma(-d2, rv, e2);
+            if (q == 0) {
+                a[0] = d0 * sc, a[1] = d1 * sc, a[2] = d2 * sc;
+                jk[0] = t0 * sc, jk[1] = t1 * sc, jk[2] = t2 * sc;
+            } else {
+                a[0] = __builtin_fma(d0, sc, a[0]), a[1] = __builtin_fma(d1, sc, a[1]), a[2] = __builtin_fma(d2, sc, a[2]);
+                jk[0] = __builtin_fma(t0, sc, jk[0]), jk[1] = __builtin_fma(t1, sc, jk[1]);
+                jk[2] = __builtin_fma(t2, sc, jk[2]);
+            }
+        }
+        Xchg6::done();
+    };
+    // acceleration only: acc_only<N, false>, accumulated from zero
+    auto acc_body = [&](const double (&pos)[3], double (&a)[3]) {
+        Xchg3::put(xchg3, lane, pos);
+        a[0] = a[1] = a[2] = 0.0;
+#pragma unroll
+        for (int q = 0; q < N - 1; q++) {
+            double pj[3];
+            Xchg3::get(xchg3, base + (q < b ? q : q + 1), pj);
+            const double d0 = pj[0] - pos[0], d1 = pj[1] - pos[1], d2 = pj[2] - pos[2];
+            const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+            const double y = rsqrt_full(r2);
+            const double rinv = y * (y * y);
+            const double sc = rinv * mo[q];
+            a[0] = __builtin_fma(d0, sc, a[0]);
+            a[1] = __builtin_fma(d1, sc, a[1]);
+            a[2] = __builtin_fma(d2, sc, a[2]);
+        }
+        Xchg3::done();
+    };
+    // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
+    BodyMonitor<N, MONB> monitor;
+    monitor.init(t);
+    auto call_monitor = [&](const bool take_part) {
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+                [](bool, bool) {});
+    };
+
+    unsigned long long steps = 0;
+    const bool mine = valid && state == SWARM_HIP_ACTIVE; // only these systems are integrated and stored
+    if (__any(mine)) {
+        const double dest = ip.destination_time;
+        // HermitePropagator::init, hermite_propagator.hpp:77-82: (acc0, jerk0) carried across steps
+        double a0[3], j0[3];
+        StepConsts k;
+        if (KIND == SWARM_HIP_HERMITE_PROP) {
+            accjerk_body(p, v, a0, j0);
+            k.set(ip.time_step);
+        }
+        bool live = mine;
+        // Every lane walks through every step of the slowest system of its wave (the exchange needs all lanes); a
+        // system that is done, or was not ACTIVE at launch, computes and discards.
+        for (int iter = 0; iter < ip.max_iterations && __any(live); iter++) {
+            double max_timestep;
+            {
+#pragma clang fp contract(off)
+                max_timestep = dest - t;
+            }
+            double np[3], nv[3], h;
+            if (KIND == SWARM_HIP_EULER) { // EulerPropagator::advance, euler.hpp:101-122
+                h = fmin(ip.time_step, max_timestep);
+                double a[3], jk[3];
+                accjerk_body(p, v, a, jk);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    np[c] = p[c], nv[c] = v[c];
+                    euler_advance(h, a[c], jk[c], np[c], nv[c]);
+                }
+            } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
+                h = fmin(ip.time_step, max_timestep);
+                if (h != k.h) k.set(h);
+                double pp[3], pv[3], c0[3], dd0[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { // hermite_step<N>, predictor
+                    pp[c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[c], a0[c]), v[c]), p[c]);
+                    pv[c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[c], a0[c]), v[c]);
+                    np[c] = pp[c];
+                    nv[c] = pv[c];
+                    c0[c] = k.kp_j0 * j0[c];
+                    pp[c] = __builtin_fma(k.kp_a, a0[c], pp[c]);
+                    dd0[c] = __builtin_fma(k.kv_a, a0[c], k.kv_j0 * j0[c]);
+                    if (FOLD) pv[c] = pv[c] + dd0[c];
+                }
+                double a1[3], j1[3];
+#pragma unroll
+                for (int round = 0; round < 2; round++) {
+                    accjerk_body(np, nv, a1, j1);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        np[c] = __builtin_fma(-k.kp_a, a1[c], pp[c]) + __builtin_fma(k.kp_j1, j1[c], c0[c]);
+                        nv[c] = FOLD ? pv[c] + __builtin_fma(-k.kv_a, a1[c], k.kv_j1 * j1[c])
+                                     : pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) a0[c] = live ? a1[c] : a0[c], j0[c] = live ? j1[c] : j0[c];
+            } else { // MidpointPropagator::advance, midpoint.hpp:106-160
+                const double H = fmin(max_timestep, ip.time_step);
+                const int n = 4;
+                const double hs = H / n;
+                h = H;
+                double p_i[3], p_im1[3], p_im2[3], v_i[3], v_im1[3], v_im2[3], a[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) p_im1[c] = p[c], v_im1[c] = v[c];
+                acc_body(p_im1, a);
+#pragma unroll
+                for (int c = 0; c < 3; c++) midpoint_first(hs, p_im1[c], v_im1[c], a[c], p_i[c], v_i[c]);
+#pragma unroll
+                for (int i = 2; i <= n; i++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        p_im2[c] = p_im1[c], p_im1[c] = p_i[c];
+                        v_im2[c] = v_im1[c], v_im1[c] = v_i[c];
+                    }
+                    acc_body(p_im1, a);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) midpoint_next(hs, p_im2[c], v_im2[c], v_im1[c], a[c], p_i[c], v_i[c]);
+                }
+                acc_body(p_i, a);
+#pragma unroll
+                for (int c = 0; c < 3; c++) midpoint_last(hs, p_i[c], p_im1[c], v_i[c], v_im1[c], a[c], np[c], nv[c]);
+            }
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) p[c] = np[c], v[c] = nv[c];
+                t += h;
+                steps++;
+            }
+            if (EJ) call_monitor(live); // generic_gpu_bppt_integrator.hpp:189-224
+            if (live && state == SWARM_HIP_ACTIVE && t >= dest) state = SWARM_HIP_INACTIVE;
+            live = live && state == SWARM_HIP_ACTIVE;
+        }
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                row[c * W] = p[c];
+                row[(3 + c) * W] = v[c];
+            }
+            if (b == 0) {
+                e.sysd[chunk * e.nsf * W + sl] = t;
+                e.sysi[chunk * 2 * W + sl] = state;
+            }
+        }
+    }
+    if (valid && b == 0) {
+        if (cnt.accepted) cnt.accepted[sys] += steps;
+        if (cnt.attempted) cnt.attempted[sys] += steps;
+    }
+}
+
+// one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
+template <int N, int KIND>
+static int launch_body_n(const LaunchCtx &c) {
+    constexpr int G = W / N;
+    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+#define SWH_LAUNCH_BODY(M) \
+    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    switch (body_monitor_of(c.mp)) {
+    case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
+    case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
+    case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;
+    default: SWH_LAUNCH_BODY(MONB_OFF); break;
+    }
+#undef SWH_LAUNCH_BODY
+    return check_launch("propagator (lane per body) kernel launch");
+}
+
+int launch_prop_body(const LaunchCtx &c, int integrator) {
+    switch (integrator) {
+    case SWARM_HIP_EULER: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_EULER>(c))); break;
+    case SWARM_HIP_MIDPOINT: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_MIDPOINT>(c))); break;
+    case SWARM_HIP_HERMITE_PROP: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_HERMITE_PROP>(c))); break;
+    default: set_error("no lane-per-body kernel for propagator id %d", integrator); return SWARM_HIP_EINVAL;
+    }
+    return SWARM_HIP_OK;
+}
+
+} // namespace swh

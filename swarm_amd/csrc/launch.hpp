@@ -27,6 +27,7 @@ int launch_hermite_mce(const LaunchCtx &c); // `hermite` + mce_stat (plugins/her
 int launch_rkck(const LaunchCtx &c, bool adaptive);
 int launch_rkck_body(const LaunchCtx &c, bool adaptive); // one lane per body, small ensembles (kernels_rkck_body.hip)
 int launch_generic(const LaunchCtx &c, int integrator);
+int launch_prop_body(const LaunchCtx &c, int integrator); // euler, midpoint, hermite_prop: one lane per body
 int launch_mvs_body(const LaunchCtx &c); // one lane per body, small ensembles (kernels_mvs_body.hip)
 // Gauss IRK; method = stages (2, 4, 6); cpu_rules = irk2_cpu's iteration constants and failure rule
 int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules);

@@ -40,6 +40,10 @@ WORKLOADS = {
                        "deactivate_on_ejection": "1", "rmax": "1000"}),
     # Gauss IRK, test/integrators/irk2.cfg step
     "irk2": dict(integrator="irk2", nsys=65536, nbod=3, T=10.0, cfg={"time_step": "0.01"}),
+    # the tutorial propagators at the time step of the reference's test/integrators/*.cfg
+    "euler": dict(integrator="euler", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
+    "midpoint": dict(integrator="midpoint", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
+    "hermite_prop": dict(integrator="hermite_prop", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
     "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
                      cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
     # C3 where it is divergent: geometrically scaled systems (size factor 0.03 .. 1, dynamical times spread over a
