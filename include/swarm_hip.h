@@ -126,7 +126,7 @@ typedef struct swarm_hip_launch {
     int32_t log_occultations;              /* log_occultations= (default 0)              */
     int32_t lane_mode;                     /* 0 = choose by nbod and nsys; 1 = one lane per system; 2 = one lane
                                               per body (hermite, hermite_adap, mvs, rkck_*, euler, midpoint,
-                                              hermite_prop: small ensembles;
+                                              verlet, hermite_prop: small ensembles;
                                               irk2 from nbod 4 and rkck_* from nbod 9 on at every size; each
                                               with a no-op monitor, stop_on_ejection, log_time_interval or the
                                               ejection-or-close-encounter composite without printing; ignored

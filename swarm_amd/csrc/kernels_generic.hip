@@ -167,28 +167,18 @@ __device__ __forceinline__ void mvs_drift(State<N> &s, double hby2, double inv_m
 // GravitationAcc::one_over_r (gravitation_acc.hpp:78-93), which returns |dx r^-3|^2 = r^-4.
 template <int N>
 __device__ __forceinline__ double verlet_timestep(const State<N> &s, const IntParams &ip) {
+#pragma clang fp contract(off)
     double factor = 0.;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
         for (int j = 1; j < N; ++j) {
             if (i == j) continue;
-            const double dx0 = s.p[j][0] - s.p[i][0], dx1 = s.p[j][1] - s.p[i][1], dx2 = s.p[j][2] - s.p[i][2];
-            const double r2 = dx0 * dx0 + dx1 * dx1 + dx2 * dx2;
-            const double y = rsqrt_full(r2);
-            const double am = y * (y * y);
-            double oor = 0.;
-            oor += (dx0 * am) * (dx0 * am);
-            oor += (dx1 * am) * (dx1 * am);
-            oor += (dx2 * am) * (dx2 * am);
-            factor += (s.m[i] + s.m[j]) * oor * oor * oor;
+            factor = factor + verlet_pair_term(s.p[j][0] - s.p[i][0], s.p[j][1] - s.p[i][1], s.p[j][2] - s.p[i][2],
+                                               s.m[i] + s.m[j]);
         }
     }
-    factor *= ip.timestep_scale * ip.timestep_scale;
-    factor += 1.;
-    factor = rsqrt_full(factor);
-    factor *= ip.max_timestep;
-    return factor;
+    return verlet_step_of(factor, ip.timestep_scale, ip.max_timestep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,20 +290,18 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
 #pragma unroll
                 for (int b = 0; b < N; b++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) s.p[b][c] = s.p[b][c] + h_first_half * s.v[b][c];
+                    for (int c = 0; c < 3; c++) verlet_first(h_first_half, s.v[b][c], s.p[b][c]);
                 acc_only<N, false>(s.p, s.m, acc);
                 timestep = verlet_timestep(s, ip);
                 const double h_second_half = (!WHOLE || live) ? 0.5 * timestep : 0.0;
 #pragma unroll
                 for (int b = 0; b < N; b++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        double vel = s.v[b][c] + h_first_half * acc[b][c];
-                        vel = vel + h_second_half * acc[b][c];
-                        s.v[b][c] = vel;
-                        s.p[b][c] = s.p[b][c] + h_second_half * vel;
-                    }
-                s.t += h_first_half + h_second_half;
+                    for (int c = 0; c < 3; c++) verlet_second(h_first_half, h_second_half, acc[b][c], s.p[b][c], s.v[b][c]);
+                {
+#pragma clang fp contract(off)
+                    s.t = s.t + (h_first_half + h_second_half);
+                }
             } else { // MidpointPropagator::advance, midpoint.hpp:106-160
                 const double H = (!WHOLE || live) ? fmin(max_timestep, ip.time_step) : 0.0;
                 const int n = 4;
@@ -431,16 +419,18 @@ static bool small_mvs_ensemble(const LaunchCtx &c) {
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
 }
 
-// euler, midpoint, hermite_prop: one lane per body (kernels_prop_body.hip) for small ensembles.  Measured crossovers
-// (profiles/r2/prop_lane_sweep.txt): the lane-per-system kernels take the same time from 2048 to 65536 systems (one
-// wavefront per SIMD at most), the lane-per-body kernels win below ~16384 systems from nbod 6 on (nbod 10, 2048
-// systems: 4x), and at nbod 3 only hermite_prop gains anything.
+// euler, midpoint, verlet, hermite_prop: one lane per body (kernels_prop_body.hip) for small ensembles.  Measured
+// crossovers (profiles/r2/prop_lane_sweep.txt): the lane-per-system kernels take the same time from 2048 to 65536
+// systems (one wavefront per SIMD at most), the lane-per-body kernels win below ~16384 systems from nbod 4 on (nbod 10,
+// 2048 systems: 4-5x); at nbod 3 only hermite_prop gains anything; verlet, whose lanes also add up the system's
+// time-step sum, from nbod 5 on.
 static bool prop_body_selected(const LaunchCtx &c, int integrator) {
     if (body_monitor_of(c.mp) == MONB_NONE) return false;
     if (c.lane_mode != 0) return c.lane_mode == 2;
-    const int nbod = c.ens.nbod;
-    if (nbod == 3) return integrator == SWARM_HIP_HERMITE_PROP && c.ens.nsys <= 8192;
-    return c.ens.nsys <= (nbod < 6 ? 8192 : 16384);
+    const int nbod = c.ens.nbod, nsys = c.ens.nsys;
+    if (integrator == SWARM_HIP_VERLET) return nbod >= 5 && nsys <= (nbod < 8 ? 8192 : 16384);
+    if (nbod == 3) return integrator == SWARM_HIP_HERMITE_PROP && nsys <= 8192;
+    return nsys <= 16384;
 }
 
 int launch_generic(const LaunchCtx &c, int integrator) {
@@ -457,6 +447,7 @@ int launch_generic(const LaunchCtx &c, int integrator) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_EULER>(c)));
         break;
     case SWARM_HIP_VERLET:
+        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_VERLET>(c)));
         break;
     case SWARM_HIP_MIDPOINT:

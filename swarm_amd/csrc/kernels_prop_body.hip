@@ -1,6 +1,7 @@
-// kernels_prop_body.hip -- the tutorial propagators euler (third-order Taylor), midpoint (modified midpoint, 4 substeps)
-// and hermite_prop (PEC2 Hermite as a propagator) of generic<Propagator,Monitor,Gravitation>::kernel
-// (swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238, propagators/{euler,midpoint,hermite_propagator}.hpp) with ONE
+// kernels_prop_body.hip -- the tutorial propagators euler (third-order Taylor), midpoint (modified midpoint, 4 substeps),
+// verlet (leapfrog with its own step) and hermite_prop (PEC2 Hermite as a propagator) of
+// generic<Propagator,Monitor,Gravitation>::kernel
+// (swarm/gpu/generic_gpu_bppt_integrator.hpp:137-238, propagators/{euler,midpoint,verlet,hermite_propagator}.hpp) with ONE
 // LANE PER BODY, for small ensembles -- the layout of kernels_hermite_body.hip: floor(64/nbod) systems per wavefront,
 // one wavefront per workgroup, a lane advances its own body and sums the forces of its partners, whose positions
 // (and velocities) it reads from rows in LDS (LaneExchange).
@@ -8,7 +9,9 @@
 // Arithmetic is that of the lane-per-system kernel (kernels_generic.hip) operation for operation: forces as
 // accjerk<N> / acc_only<N, false> accumulate them per body, the per-coordinate updates from propagators_common.hpp
 // and hermite_step<N>; both kernels give bit-identical ensembles (tests/test_gpu_prop_body.py).  Monitors:
-// body_monitor.hpp.  (verlet stays one lane per system: its time step is one sum over all ordered pairs of a system.)
+// body_monitor.hpp.  Verlet's time step is one sum over all ordered pairs (i, j >= 1) of a system in a fixed order: a
+// lane forms the terms of its own row, the rows go through LDS and every lane of the system adds all of them in that
+// order.
 #include "body_monitor.hpp"
 #include "launch.hpp"
 #include "propagators_common.hpp"
@@ -103,6 +106,34 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
         }
         Xchg3::done();
     };
+    // VerletPropagator::calc_timestep: my row of pair terms (partner planets only) into LDS, then the whole sum
+    __shared__ double pair_terms[KIND == SWARM_HIP_VERLET ? N - 1 : 1][W];
+    auto verlet_timestep_body = [&](const double (&pos)[3]) -> double {
+        Xchg3::put(xchg3, lane, pos);
+#pragma unroll
+        for (int q = 0; q < N - 1; q++) {
+            double pj[3];
+            Xchg3::get(xchg3, base + (q < b ? q : q + 1), pj);
+            // slot q is partner j = q (j < b) or q + 1; the star's lane has planets in every slot, a planet's slot 0
+            // is the star, which is no term
+            pair_terms[KIND == SWARM_HIP_VERLET ? q : 0][lane] =
+                verlet_pair_term(pj[0] - pos[0], pj[1] - pos[1], pj[2] - pos[2], m_own + mo[q]);
+        }
+        __syncthreads(); // a single wavefront: the terms are stored before they are read
+        double sum = 0.0;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int i = 0; i < N; i++)
+#pragma unroll
+                for (int j = 1; j < N; j++) {
+                    if (i == j) continue;
+                    sum = sum + pair_terms[KIND == SWARM_HIP_VERLET ? (j < i ? j : j - 1) : 0][base + i];
+                }
+        }
+        Xchg3::done();
+        return verlet_step_of(sum, ip.timestep_scale, ip.max_timestep);
+    };
     // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
@@ -122,6 +153,8 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             accjerk_body(p, v, a0, j0);
             k.set(ip.time_step);
         }
+        double timestep = 0.0;
+        if (KIND == SWARM_HIP_VERLET) timestep = verlet_timestep_body(p);
         bool live = mine;
         // Every lane walks through every step of the slowest system of its wave (the exchange needs all lanes); a
         // system that is done, or was not ACTIVE at launch, computes and discards.
@@ -169,6 +202,24 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
                 }
 #pragma unroll
                 for (int c = 0; c < 3; c++) a0[c] = live ? a1[c] : a0[c], j0[c] = live ? j1[c] : j0[c];
+            } else if (KIND == SWARM_HIP_VERLET) { // VerletPropagator::advance, verlet.hpp:139-175 (the step is not clipped)
+                const double h_first_half = 0.5 * timestep;
+                double a[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    np[c] = p[c], nv[c] = v[c];
+                    verlet_first(h_first_half, v[c], np[c]);
+                }
+                acc_body(np, a);
+                const double next = verlet_timestep_body(np);
+                const double h_second_half = 0.5 * next;
+#pragma unroll
+                for (int c = 0; c < 3; c++) verlet_second(h_first_half, h_second_half, a[c], np[c], nv[c]);
+                {
+#pragma clang fp contract(off)
+                    h = h_first_half + h_second_half;
+                }
+                if (live) timestep = next;
             } else { // MidpointPropagator::advance, midpoint.hpp:106-160
                 const double H = fmin(max_timestep, ip.time_step);
                 const int n = 4;
@@ -198,7 +249,10 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             if (live) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) p[c] = np[c], v[c] = nv[c];
-                t += h;
+                {
+#pragma clang fp contract(off)
+                    t = t + h;
+                }
                 steps++;
             }
             if (EJ) call_monitor(live); // generic_gpu_bppt_integrator.hpp:189-224
@@ -245,6 +299,7 @@ int launch_prop_body(const LaunchCtx &c, int integrator) {
     case SWARM_HIP_EULER: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_EULER>(c))); break;
     case SWARM_HIP_MIDPOINT: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_MIDPOINT>(c))); break;
     case SWARM_HIP_HERMITE_PROP: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_HERMITE_PROP>(c))); break;
+    case SWARM_HIP_VERLET: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_VERLET>(c))); break;
     default: set_error("no lane-per-body kernel for propagator id %d", integrator); return SWARM_HIP_EINVAL;
     }
     return SWARM_HIP_OK;

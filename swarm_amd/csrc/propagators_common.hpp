@@ -1,5 +1,5 @@
 // propagators_common.hpp -- the per-coordinate arithmetic of the tutorial propagators (propagators/euler.hpp:101-122,
-// midpoint.hpp:106-160), shared by the lane-per-system kernel (kernels_generic.hip) and the lane-per-body kernel
+// midpoint.hpp:106-160, verlet.hpp:112-175), shared by the lane-per-system kernel (kernels_generic.hip) and the lane-per-body kernel
 // (kernels_prop_body.hip): every floating-point operation explicit, so both produce the same bits.
 #pragma once
 #include "device_common.hpp"
@@ -36,6 +36,37 @@ __device__ __forceinline__ void midpoint_last(const double h, const double p_i, 
 #pragma clang fp contract(off)
     p = 0.5 * __builtin_fma(h, v_i, p_i + p_im1);
     v = 0.5 * __builtin_fma(h, acc, v_i + v_im1);
+}
+
+// VerletPropagator::calc_timestep (verlet.hpp:112-137): the term of one ordered pair (i, j), (m_i + m_j) u^3 with
+// u = |d r^-3|^2 as GravitationAcc::one_over_r forms it (gravitation_acc.hpp:78-93); even in the sign of d
+__device__ __forceinline__ double verlet_pair_term(const double d0, const double d1, const double d2, const double msum) {
+#pragma clang fp contract(off)
+    const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+    const double y = rsqrt_full(r2);
+    const double am = y * (y * y);
+    const double a0 = d0 * am, a1 = d1 * am, a2 = d2 * am;
+    const double u = __builtin_fma(a2, a2, __builtin_fma(a1, a1, a0 * a0));
+    return ((msum * u) * u) * u;
+}
+// ... and the step from the sum of the terms (added one by one, i outer over all bodies, j inner over the planets)
+__device__ __forceinline__ double verlet_step_of(const double sum, const double timestep_scale, const double max_timestep) {
+#pragma clang fp contract(off)
+    return rsqrt_full(__builtin_fma(sum, timestep_scale * timestep_scale, 1.0)) * max_timestep;
+}
+// VerletPropagator::advance (verlet.hpp:139-175), one coordinate: half a drift with the old step, ...
+__device__ __forceinline__ void verlet_first(const double h_first_half, const double v, double &p) {
+#pragma clang fp contract(off)
+    p = __builtin_fma(h_first_half, v, p);
+}
+// ... the kick in two halves (old and new step) and half a drift with the new one
+__device__ __forceinline__ void verlet_second(const double h_first_half, const double h_second_half, const double acc,
+                                              double &p, double &v) {
+#pragma clang fp contract(off)
+    double vel = __builtin_fma(h_first_half, acc, v);
+    vel = __builtin_fma(h_second_half, acc, vel);
+    v = vel;
+    p = __builtin_fma(h_second_half, vel, p);
 }
 
 } // namespace swh

@@ -44,6 +44,7 @@ WORKLOADS = {
     "euler": dict(integrator="euler", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
     "midpoint": dict(integrator="midpoint", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
     "hermite_prop": dict(integrator="hermite_prop", nsys=65536, nbod=3, T=0.5, cfg={"time_step": "0.001"}),
+    "verlet": dict(integrator="verlet", nsys=65536, nbod=3, T=0.5, cfg={"max_timestep": "0.001", "timestep_scale": "1.0"}),
     "c5_nolog": dict(integrator="hermite_adap", nsys=65536, nbod=4, T=100.0,
                      cfg={"time_step_factor": "170e-4", "min_time_step": "0.00001"}),
     # C3 where it is divergent: geometrically scaled systems (size factor 0.03 .. 1, dynamical times spread over a
