@@ -223,6 +223,45 @@ __device__ __forceinline__ void acc_only(const double (&p)[N][3], const double (
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ghost lanes.  A fixed-step kernel with nothing to monitor lets the lanes whose systems are not ACTIVE sit the launch
+// out.  Where that leaves 8 or fewer lanes of a wavefront enabled, FP64 instructions issue at a third of their rate
+// (DESIGN 3.11): enough of the idle lanes then ride along as ghosts -- copies of the wave's active system with the
+// earliest time (the one that takes the most steps), so that they do exactly what that lane does and bring no
+// divergence of their own; they store nothing at the end.  Called by every lane of the wavefront that holds a system;
+// returns whether this lane is a ghost.  A full wave of active systems pays one ballot.
+template <int N>
+__device__ __forceinline__ bool take_ghosts(const bool mine, State<N> &s) {
+#ifdef SWH_NO_GHOSTS // A/B builds (tools/variant.sh)
+    return false;
+#endif
+    const unsigned long long active = __ballot(mine);
+    const int nlive = __popcll(active);
+    if (nlive == 0 || nlive > 8) return false; // wave-uniform
+    const unsigned long long idle = __ballot(!mine);
+    const int rank = __popcll(idle & ((1ull << (threadIdx.x % W)) - 1)); // my place among the idle lanes
+    int src = __ffsll((long long)active) - 1;
+    double t0 = __shfl(s.t, src);
+    for (unsigned long long m = active & (active - 1); m; m &= m - 1) { // at most 7 more
+        const int l = __ffsll((long long)m) - 1;
+        const double tl = __shfl(s.t, l);
+        if (tl < t0) t0 = tl, src = l;
+    }
+    const bool ghost = !mine && rank < 9 - nlive;
+#pragma unroll
+    for (int b = 0; b < N; b++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double x = __shfl(s.p[b][c], src), y = __shfl(s.v[b][c], src);
+            if (ghost) s.p[b][c] = x, s.v[b][c] = y;
+        }
+        const double m = __shfl(s.m[b], src);
+        if (ghost) s.m[b] = m;
+    }
+    if (ghost) s.t = t0, s.state = SWARM_HIP_ACTIVE;
+    return ghost;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Lane-per-body kernels (one wavefront per workgroup): K doubles per lane handed to the other lanes of the wavefront
 // through LDS -- one or two wide stores per lane and K/2 16-byte loads per partner instead of 2 K ds_bpermute_b32.
 // The exchange is what bounds those kernels at saturation (irk2, 65536 x 6: 8.29 -> 7.75 ms; 2048 x 6: 1.135 -> 1.085).

@@ -220,8 +220,10 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
     // start times differ, and the selects cost the uniform case 3 % (C4 shard 10.76 -> 11.11 ms).
     constexpr bool WHOLE = MON != MON_OFF || KIND == SWARM_HIP_VERLET;
     const bool mine = s.state == SWARM_HIP_ACTIVE; // only these systems are converted, integrated and stored
-    if (WHOLE ? __any(mine) : mine) {
-        bool live = mine;
+    // ... and where that leaves a wave 8 lanes or fewer, ghosts ride along (device_common.hpp)
+    const bool ghost = !WHOLE && take_ghosts<N>(mine, s);
+    if (WHOLE ? __any(mine) : (mine || ghost)) {
+        bool live = mine || ghost;
         MonState ms;
         mon_init(ms, s);
         double acc[N][3];
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
         if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
         if (mine) store_state(e, gid, s);
     }
+    if (ghost) return;
     if (cnt.accepted) cnt.accepted[gid] += steps;
     if (cnt.attempted) cnt.attempted[gid] += steps;
 }

@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
     // nothing to monitor -- Hermite.cfg as shipped, the headline: its lanes all take the same steps unless their start
     // times differ, and the extra control flow cost that kernel 3 % (16.88 -> 17.38 ms, A/B on one box).
     constexpr bool WHOLE = ADAPTIVE || MON != MON_OFF;
+    // ... but a wave that would start with 8 or fewer lanes takes ghosts along (device_common.hpp)
+    const bool ghost = !WHOLE && take_ghosts<N>(s.state == SWARM_HIP_ACTIVE, s);
     if (WHOLE ? __any(s.state == SWARM_HIP_ACTIVE) : (s.state == SWARM_HIP_ACTIVE)) {
         double fa[2][N][3], fj[2][N][3]; // ping-pong force buffers
         accjerk<N>(s.p, s.v, s.m, fa[0], fj[0]);
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
                 for (int c = 0; c < 3; c++) fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
         }
     }
+    if (ghost) return;
     if (steps || s.state != state_in) store_state(e, gid, s);
     if (cnt.accepted) cnt.accepted[gid] += steps;
     if (cnt.attempted) cnt.attempted[gid] += steps;

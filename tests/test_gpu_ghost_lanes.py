@@ -1,0 +1,49 @@
+"""Ghost lanes (device_common.hpp ghost_lane): a fixed-step kernel with nothing to monitor takes idle lanes along when 8
+or fewer systems of a wavefront are ACTIVE, so that its FP64 instructions issue at full rate.  Ghosts store nothing:
+the ACTIVE systems must come out exactly as from a dense run, the others untouched, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import perturbed, to_host
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "hermite": {"time_step": "0.001"},
+    "mvs": {"time_step": "0.001"},
+    "euler": {"time_step": "0.001"},
+    "midpoint": {"time_step": "0.001"},
+    "hermite_prop": {"time_step": "0.001"},
+}
+
+
+def run(S, host, cfg, dest):
+    integ = S.Integrator.create(S.config(cfg))
+    integ.set_ensemble(host)
+    integ.set_destination_time(dest)
+    integ.enable_step_counters()
+    integ.integrate()
+    return integ.step_counts()[0]
+
+
+@pytest.mark.parametrize("plugin", sorted(CASES))
+@pytest.mark.parametrize("nbod,nsys,keep", [(3, 1000, 16), (6, 333, 9), (4, 130, 64), (8, 70, 8)])
+def test_sparse_ensemble_equals_dense_run(gpu, oracle, plugin, nbod, nsys, keep):
+    S, O = gpu, oracle
+    e = perturbed(O, nsys, nbod, seed=900 + nbod)
+    e.time[:] = np.linspace(0.0, 0.02, nsys)            # ghosts start from the earliest active time of their wave
+    cfg = dict(CASES[plugin], integrator=plugin, lane_mode="1")
+    dense = to_host(S, e)
+    cd = run(S, dense, cfg, 0.1003)
+    sp = e.clone()
+    active = np.zeros(nsys, bool)
+    active[::keep] = True
+    sp.state[~active] = O.DISABLED
+    sp.pos[5::7] *= 1e150                               # what a ghost may find in a disabled system: overflowing forces
+    sp.pos[active] = e.pos[active]
+    sparse = to_host(S, sp)
+    cs = run(S, sparse, cfg, 0.1003)
+    for k in ("pos", "vel", "time", "state"):
+        assert (getattr(sparse, k)[active] == getattr(dense, k)[active]).all(), k
+        assert (getattr(sparse, k)[~active] == getattr(sp, k)[~active]).all(), k
+    assert (cs[active] == cd[active]).all() and (cs[~active] == 0).all()

@@ -118,7 +118,7 @@ def lane_utilisation(att):
 
 
 def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0, spread=0.0, shuffle=False,
-            pinned=False, host_to_host=True, extra_cfg=None, warm=False):
+            pinned=False, host_to_host=True, extra_cfg=None, warm=False, sparse=0):
     """kernel time of one launch (HIP events on the launch stream), best of `reps`; step counts; optional
     host-to-host time of integrate()"""
     w = dict(WORKLOADS[workload])
@@ -126,6 +126,9 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
     S.capi.check(S.capi.lib.swarm_hip_init(0))
     L = S.capi.lib
     host0 = make_ensemble(w, nsys, nbod, spread, shuffle)
+    if sparse > 1:                         # every `sparse`-th system ACTIVE, the others DISABLED: thin wavefronts
+        host0.state[:] = S.capi.DISABLED
+        host0.state[::sparse] = S.capi.ACTIVE
     cfg = dict(w["cfg"], integrator=w["integrator"], lane_mode=str(lane_mode))
     cfg.update(extra_cfg or {})
     res = []
@@ -253,10 +256,11 @@ def main():
     ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--warm", action="store_true", help="enqueue the same launch on a copy directly ahead of the timed one")
+    ap.add_argument("--sparse", type=int, default=0, help="only every K-th system ACTIVE, the others DISABLED")
     ap.add_argument("cfg", nargs="*", help="extra key=value configuration pairs")
     a = ap.parse_args()
     print(json.dumps(measure(a.workload, a.nsys, a.nbod, a.T, a.reps, a.block, a.lane_mode, a.spread, a.shuffle,
-                             a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg), a.warm)))
+                             a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg), a.warm, a.sparse)))
 
 
 if __name__ == "__main__":
