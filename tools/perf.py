@@ -129,6 +129,11 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
     if sparse > 1:                         # every `sparse`-th system ACTIVE, the others DISABLED: thin wavefronts
         host0.state[:] = S.capi.DISABLED
         host0.state[::sparse] = S.capi.ACTIVE
+    elif sparse < 0:                       # one thin wavefront (4 ACTIVE systems) in every |sparse|, the others full
+        st = host0.state.reshape(-1, 64) if nsys % 64 == 0 else None
+        thin = np.arange(nsys // 64) % (-sparse) == 0
+        st[thin, :] = S.capi.DISABLED
+        st[thin, ::16] = S.capi.ACTIVE
     cfg = dict(w["cfg"], integrator=w["integrator"], lane_mode=str(lane_mode))
     cfg.update(extra_cfg or {})
     res = []
@@ -256,7 +261,7 @@ def main():
     ap.add_argument("--pinned", action="store_true", help="host ensemble in page-locked memory (swarm::hostEnsemble)")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--warm", action="store_true", help="enqueue the same launch on a copy directly ahead of the timed one")
-    ap.add_argument("--sparse", type=int, default=0, help="only every K-th system ACTIVE, the others DISABLED")
+    ap.add_argument("--sparse", type=int, default=0, help="K > 1: only every K-th system ACTIVE, the others DISABLED; K < 0: every |K|-th wavefront thin (4 ACTIVE), the others full")
     ap.add_argument("cfg", nargs="*", help="extra key=value configuration pairs")
     a = ap.parse_args()
     print(json.dumps(measure(a.workload, a.nsys, a.nbod, a.T, a.reps, a.block, a.lane_mode, a.spread, a.shuffle,
