@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void irk2_kernel(EnsView e, IntParams ip, MonP
 
     unsigned long long steps = 0;
     bool rewritten = false;
+    // nothing to monitor: a wave that starts with 8 or fewer active systems takes ghosts along (device_common.hpp)
+    const bool ghost = MON == MON_OFF && take_ghosts<N>(s.state == SWARM_HIP_ACTIVE, s);
     if (s.state == SWARM_HIP_ACTIVE) {
         using X = IrkCoord<NS>; // the per-coordinate arithmetic, shared with kernels_irk2_body.hip
         double F[NS][N][3], ZQ[NS][N][3], FS[N][3], PS[N][3];
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void irk2_kernel(EnsView e, IntParams ip, MonP
                     }
                 } else { // L231-242
                     if (nit >= nitmax) {
-                        SWH_LPRINTF(lg, "no convergence of iteration: %d\n", parg(nit));
+                        if (!ghost) SWH_LPRINTF(lg, "no convergence of iteration: %d\n", parg(nit));
                         s.state = SWARM_HIP_DISABLED;
                         break;
                     }
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256) void irk2_kernel(EnsView e, IntParams ip, MonP
             }
         }
     }
+    if (ghost) return;
     if (steps || s.state != state_in) store_state(e, gid, s);
     if (rewritten) mce_store_masses<N>(e, gid, s);
     if (cnt.accepted) cnt.accepted[gid] += steps;

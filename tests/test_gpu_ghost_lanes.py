@@ -14,6 +14,7 @@ CASES = {
     "euler": {"time_step": "0.001"},
     "midpoint": {"time_step": "0.001"},
     "hermite_prop": {"time_step": "0.001"},
+    "irk2": {"time_step": "0.01"},
 }
 
 
