@@ -1,6 +1,7 @@
-"""Ghost lanes (device_common.hpp ghost_lane): a fixed-step kernel with nothing to monitor takes idle lanes along when 8
-or fewer systems of a wavefront are ACTIVE, so that its FP64 instructions issue at full rate.  Ghosts store nothing:
-the ACTIVE systems must come out exactly as from a dense run, the others untouched, bit for bit."""
+"""Ghost lanes (device_common.hpp take_ghosts): a fixed-step kernel with nothing to monitor turns idle lanes into copies of
+one of its active systems when 8 or fewer systems of a wavefront are ACTIVE, so that its FP64 instructions issue at
+full rate.  Ghosts store and count nothing: the ACTIVE systems must come out exactly as from a dense run, the others
+untouched, bit for bit."""
 import numpy as np
 import pytest
 
@@ -32,7 +33,7 @@ def run(S, host, cfg, dest):
 def test_sparse_ensemble_equals_dense_run(gpu, oracle, plugin, nbod, nsys, keep):
     S, O = gpu, oracle
     e = perturbed(O, nsys, nbod, seed=900 + nbod)
-    e.time[:] = np.linspace(0.0, 0.02, nsys)            # ghosts start from the earliest active time of their wave
+    e.time[:] = np.linspace(0.0, 0.02, nsys)            # ghosts copy the active system of their wave with the earliest time
     cfg = dict(CASES[plugin], integrator=plugin, lane_mode="1")
     dense = to_host(S, e)
     cd = run(S, dense, cfg, 0.1003)
@@ -40,7 +41,7 @@ def test_sparse_ensemble_equals_dense_run(gpu, oracle, plugin, nbod, nsys, keep)
     active = np.zeros(nsys, bool)
     active[::keep] = True
     sp.state[~active] = O.DISABLED
-    sp.pos[5::7] *= 1e150                               # what a ghost may find in a disabled system: overflowing forces
+    sp.pos[5::7] *= 1e150                               # disabled systems may hold anything; a ghost must not use it
     sp.pos[active] = e.pos[active]
     sparse = to_host(S, sp)
     cs = run(S, sparse, cfg, 0.1003)
