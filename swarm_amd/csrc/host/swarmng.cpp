@@ -297,7 +297,8 @@ public:
         a.integrator = ID;
         a.monitor = MON;
         int spb = cfg.optional("system_per_block", 0); // the reference's block-shape knob
-        if (spb > 0) a.block_size = std::max(64, std::min(256, (spb + 63) / 64 * 64));
+        // one wavefront or four per workgroup: two or three measured up to 2x slower at one wavefront per SIMD (swarm_hip.h)
+        if (spb > 0) a.block_size = spb <= 64 ? 64 : 256;
         if (ID == SWARM_HIP_HERMITE || ID == SWARM_HIP_MVS || ID == SWARM_HIP_EULER || ID == SWARM_HIP_MIDPOINT ||
             ID == SWARM_HIP_HERMITE_PROP || ID == SWARM_HIP_IRK2 || ID == SWARM_HIP_IRK2_CPU)
             a.time_step = cfg.require("time_step", 0.0); // hermite_integrator.hpp:44-46, mvs.hpp:41-43, ...

@@ -223,7 +223,8 @@ class GpuIntegrator(Integrator):
         a.block_size = 0
         spb = cfg.optional("system_per_block", 0)
         if spb:
-            a.block_size = max(64, min(256, (spb + 63) // 64 * 64))
+            # one wavefront or four per workgroup: two or three measured up to 2x slower at one wavefront per SIMD (swarm_hip.h)
+            a.block_size = 64 if spb <= 64 else 256
         # constructor-time key checks follow each reference ctor
         if self.int_id in (capi.HERMITE, capi.MVS, capi.EULER, capi.MIDPOINT, capi.HERMITE_PROP, capi.IRK2, capi.IRK2_CPU):
             a.time_step = cfg.require("time_step", 0.0)      # hermite_integrator.hpp:44-46 etc.
