@@ -8,9 +8,11 @@ system), systems are re-activated and ONE kernel launch integrates every system 
 destination, followed by the reference's active-count check (swarm/integrator.cpp:102-117
 without the H2D/D2H copies: inputs are resident in HBM).
 
-N > 1: one process per GPU (torchrun), the ensemble is partitioned by system index, each rank
-integrates its own shard (no data-path collective); after the timed region the energy/ejection
-statistics are all-reduced and the final shards gathered over RCCL, outside the timing.
+N > 1: one process per GPU, the ensemble is partitioned by system index, each rank integrates its own shard (no
+data-path collective); after the timed region the energy/ejection statistics are all-reduced and the final shards
+gathered to rank 0 over RCCL, outside the timing.  `python bench.py --gpus N` starts the N ranks itself (child
+processes through torch.distributed.run, before this process touches torch or the GPU); under an external
+torchrun / torch.distributed.run (RANK set) it is one of the ranks.
 
 At N = 1 the JSON line also carries a "lane_per_body" block (three small measurements of the DESIGN 3.9 kernels beside
 the lane-per-system ones) and a "secondary" block: BASELINE's other single-GPU configurations (C3
@@ -19,7 +21,8 @@ hermite_adap_log 65536 x 4), one or two launches each, kernel time by HIP events
 
 --config c4 runs BASELINE configs[3] itself: mvs, time_step = 0.01, nsys = 2^20, nbod = 8 partitioned over the
 ranks (swarm_amd.parallel.run_sharded: shard_bounds, one launch loop per shard, all_gather_into_tensor of the
-statistics vector and of the three device buffers into preallocated outputs, verification on rank 0).
+statistics vector + buffer checksums, a gather of the three device buffers into a preallocated image on rank 0,
+verification there).
 """
 import argparse
 import ctypes as C
@@ -92,6 +95,24 @@ def hermite_flops(n):
     return 118 * (n * (n - 1) // 2) + 159 * n
 
 
+def launch_ranks(n):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>`
+    as a child process of this (GPU-free) one; rendezvous on 127.0.0.1 at a free port.  Rank 0's JSON line goes to
+    this process's stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +135,12 @@ def main():
                          "over gloo on host copies (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks here, as fresh child processes, BEFORE anything
+    # in this process imports torch or touches the GPU (a process that has initialised HIP must not be replaced or
+    # forked), and exit with their status.  Under torchrun / torch.distributed.run RANK is set and this is a rank.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
+
     import numpy as np
     import torch
     import swarm_amd as S
@@ -125,20 +152,27 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.rehearse_one_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d but this node has %d GPU(s) (one process per GPU; "
+                         "--rehearse-one-gpu puts every rank on cuda:0)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.rehearse_one_gpu else dev   # where collective operands live
-    dist = None
+    dist, backend = None, None
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     if world > 1 or "RANK" in os.environ:     # under torchrun the exchange runs even with one rank (RCCL rehearsal)
         import torch.distributed as dist
+        backend = "gloo" if args.rehearse_one_gpu else "nccl"
         if args.rehearse_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()
     S.capi.check(S.capi.lib.swarm_hip_init(local_rank))
     L = S.capi.lib
     if args.config == "c4":
-        return bench_c4(args, S, torch, dist, dev, cdev, rank, world)
+        return bench_c4(args, S, torch, dist, dev, cdev, rank, world, backend)
 
     nsys, nbod = args.nsys, args.nbod
     # global ensemble partitioned by system index: this rank owns [rank*nsys, (rank+1)*nsys)
@@ -218,22 +252,25 @@ def main():
                               dist=dist, device=cdev)
     gather_ms, gather_ok = None, None
     if dist is not None:
-        # final ensemble gather: a shard is a contiguous run of wave chunks, so ONE all_gather_into_tensor per device
-        # buffer into a preallocated output gives the wave-chunk image of the whole ensemble
+        # final ensemble gather: a shard is a contiguous run of wave chunks, so ONE gather per device buffer into
+        # slices of a preallocated tensor on rank 0 gives the wave-chunk image of the whole ensemble; the senders'
+        # checksums travel in one small all-gather and rank 0 checks every slice against them
         srcs = [t.to(cdev) for t in (tb, td, ti)]
-        outs = [torch.empty(world * t.numel(), dtype=t.dtype, device=cdev) for t in srcs]
+        mine = P.buffer_checksums(srcs)
+        sums = torch.empty(world * 3, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(sums, mine)
         torch.cuda.synchronize()
+        dist.barrier()
         g0 = time.perf_counter()
-        for o, t in zip(outs, srcs):
-            dist.all_gather_into_tensor(o, t)
+        outs = P.gather_to_root(srcs, dist, rank, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        # every rank: its own bytes sit at its offset; rank 0: the gathered ids are 0 .. world * nsys - 1
-        gather_ok = all(torch.equal(o[rank * t.numel():(rank + 1) * t.numel()], t) for o, t in zip(outs, srcs))
         if rank == 0:
+            got = torch.stack([P.buffer_checksums(list(o.split(t.numel()))) for o, t in zip(outs, srcs)], dim=1)
+            gather_ok = bool(torch.equal(got.cpu(), sums.reshape(world, 3).cpu()))
             ids = outs[2].view(torch.int32).reshape(-1, 2, 64)[:, 1, :].reshape(-1).cpu().numpy()
             gather_ok = gather_ok and bool((ids == np.arange(world * nsys)).all())
-        assert gather_ok, "gathered shards differ from the local ones"
+            assert gather_ok, "gathered shards differ from what the ranks sent"
 
     total_sys_steps = float(world) * nsys * steps_per_pass * args.steps
     value = total_sys_steps / elapsed
@@ -277,6 +314,9 @@ def main():
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
         out["gather_verified"] = bool(gather_ok)
+        out["gathered_bytes"] = int(world * (tb.numel() + td.numel() + ti.numel()))
+        out["exchange"] = "%s: all_reduce x 3 of the statistics, all_gather of 3 checksums, gather of body/sysd/sysi to rank 0" % backend
+        out["rccl_ranks"] = world if backend == "nccl" else 0
     if rank == 0 and world == 1 and dist is None and not args.no_secondary:
         out["secondary"] = secondary_block()
         out["lane_per_body"] = lane_per_body_block()
@@ -308,7 +348,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_c4(args, S, torch, dist, dev, cdev, rank, world):
+def bench_c4(args, S, torch, dist, dev, cdev, rank, world, backend):
     """BASELINE configs[3]: mvs, nsys = 2^20, nbod = 8, time_step = 0.01, partitioned over the ranks.  One bench step
     = the whole run (destination_time = --c4-span); `value` = system-steps of all ranks / the slowest rank's time."""
     import numpy as np
@@ -343,8 +383,7 @@ def bench_c4(args, S, torch, dist, dev, cdev, rank, world):
     total = float(nsys_total) * steps_per_system
     flops = perf.mvs_flops(nbod)
     achieved = flops * total / world / integ_s / 1e12
-    ok = bool(res["own_bytes_in_place"]) and (rank != 0 or bool(res["ids_are_arange"]))
-    assert ok, "gathered image differs from the shards"
+    assert rank != 0 or (res["checksums_match"] and res["ids_are_arange"]), "gathered image differs from the shards"
     if rank == 0:
         full = res["full"]
         assert (full.state == 1).all() and np.allclose(full.time, args.c4_span, rtol=1e-12)
@@ -362,8 +401,10 @@ def bench_c4(args, S, torch, dist, dev, cdev, rank, world):
                          "kernel": "generic_kernel<8,MVS,0>", "flop_per_system_step": flops,
                          "note": "per GPU; the time is host to host over the shard's launch loop"},
             "exchange": {"gather_ms": gather_s * 1e3, "gathered_bytes": res["gathered_bytes"],
-                         "collectives": "all_gather_into_tensor x 4 (statistics, body, sysd, sysi)",
-                         "own_bytes_in_place": True, "ids_are_arange": True},
+                         "collectives": "all_gather_into_tensor of 11 words (statistics + 3 checksums), gather to rank 0 "
+                                        "x 3 (body, sysd, sysi)" if dist is not None else "none (one rank)",
+                         "rccl_ranks": world if backend == "nccl" else 0,
+                         "checksums_match": True, "ids_are_arange": True},
             "energy": {"max_rel_err": res["stats"]["max_abs_dE_over_E"], "mean_rel_err": res["stats"]["mean_abs_dE_over_E"],
                        "n_inactive": int(res["stats"]["n_inactive"]), "n_systems": int(res["stats"]["nsys"])},
         }), flush=True)

@@ -111,14 +111,35 @@ def gather_ensemble(shard, nsys_total, dist=None, device=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # The sharded run (BASELINE configs[3]: mvs, nsys = 2^20, nbod = 8 over 8 GPUs).  Every rank owns the same number of
 # wave chunks (`capacity`; the last ranks may hold fewer real systems), integrates them with no exchange at all, and
-# then takes part in two collectives: one all_gather_into_tensor of the 8-double statistics vector of
-# swarm_hip_energy_stats, and one all_gather_into_tensor per device buffer (body, sysd, sysi) into preallocated
-# outputs.  Because a shard is a contiguous run of wave chunks, the gathered buffers ARE the wave-chunk image of the
-# whole ensemble: no unpacking step follows the collective.
+# then takes part in two exchanges: one all_gather_into_tensor of an 11-word vector (the 8 doubles of
+# swarm_hip_energy_stats + one checksum per device buffer), and one gather to rank 0 per device buffer (body, sysd,
+# sysi) into slices of a preallocated image.  Because a shard is a contiguous run of wave chunks, the gathered buffers
+# ARE the wave-chunk image of the whole ensemble: no unpacking step follows.  Only rank 0 receives the image (north_star:
+# "the final ensemble gather"): each shard crosses xGMI once, on the link between its GPU and rank 0's -- 7 links into
+# rank 0 in parallel; an all-gather would put 8 copies of the 562 MB image of C4 on the fabric for nothing.
 #
 # The device work goes through a `backend` with the five calls below.  HipShardBackend (the product) makes them C-ABI
 # calls on torch-owned device memory; tests/test_parallel_gloo.py supplies a CPU stand-in so that the same harness --
 # partition, collectives, verification -- runs under gloo without a GPU.
+
+def buffer_checksums(buffers):
+    """one int64 per buffer: the wrapping sum of its bytes read as int64 words (buffer sizes are multiples of 512)"""
+    import torch
+    return torch.stack([b.view(torch.int64).sum() for b in buffers])
+
+
+def gather_to_root(buffers, dist, rank, world, dst=0):
+    """dist.gather of every buffer into slices of one preallocated tensor per buffer on rank `dst` (RCCL: grouped
+    send/recv, the receives land in place).  Returns the list of gathered tensors on `dst`, None elsewhere."""
+    import torch
+    out = None
+    if rank == dst:
+        out = [torch.empty(world * b.numel(), dtype=b.dtype, device=b.device) for b in buffers]
+    for k, b in enumerate(buffers):
+        parts = list(out[k].split(b.numel())) if rank == dst else None
+        dist.gather(b, parts, dst=dst)
+    return out
+
 
 class HipShardBackend:
     """One rank's shard on its GPU: torch owns the bytes, libswarm_hip.so does the work."""
@@ -192,7 +213,9 @@ def run_sharded(nsys_total, make_shard, make_backend, cfg, destination_time, dis
                 sync=lambda: None, clock=None, verify=True):
     """Partition, integrate, exchange, verify.  make_shard(lo, hi) -> host ensemble of systems [lo, hi) with ids
     lo..hi-1; make_backend(capacity, nsys) -> backend.  Returns a dict with the combined statistics, the integrate
-    and gather times of this rank, and (rank 0, verify=True) the outcome of the checks on the gathered image."""
+    and gather times of this rank, and (rank 0, verify=True) the outcome of the checks on the gathered image:
+    `checksums_match` (every rank's slice of the image has the checksum that rank computed of its own buffers),
+    `ids_are_arange`, and the image as a host ensemble (`full`)."""
     import time
     import torch
     clock = clock or time.perf_counter
@@ -211,33 +234,29 @@ def run_sharded(nsys_total, make_shard, make_backend, cfg, destination_time, dis
     be.integrate(cfg, destination_time)
     sync()
     t_integrate = clock() - t0
-    # statistics: one collective
-    mine = be.stats()
+    # statistics + buffer checksums: one collective of 11 words (the checksums travel as int64 bit patterns)
+    mine = torch.cat([be.stats(), buffer_checksums(be.buffers).to(torch.int64).view(torch.float64)])
     if multi:
-        allstats = torch.empty(world * 8, dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(allstats, mine)
+        allwords = torch.empty(world * 11, dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(allwords, mine)
     else:
-        allstats = mine
-    stats = combine_stats(allstats.cpu().numpy())
-    # final shards: one collective per buffer into a preallocated image of world * capacity systems
+        allwords = mine
+    allwords = allwords.reshape(-1, 11)
+    stats = combine_stats(allwords[:, :8].cpu().numpy())
+    sums = allwords[:, 8:].contiguous().view(torch.int64)       # [world, 3]
+    # final shards: one gather per buffer into slices of a preallocated image of world * capacity systems on rank 0
     sync()
     t0 = clock()
-    if multi:
-        gathered = [torch.empty(world * b.numel(), dtype=b.dtype, device=b.device) for b in be.buffers]
-        for g, b in zip(gathered, be.buffers):
-            dist.all_gather_into_tensor(g, b)
-    else:
-        gathered = be.buffers
+    gathered = gather_to_root(be.buffers, dist, rank, world) if multi else be.buffers
     sync()
     t_gather = clock() - t0
     res = {"stats": stats, "integrate_s": t_integrate, "gather_s": t_gather, "bounds": bounds, "capacity": capacity,
-           "gathered_bytes": int(sum(g.numel() for g in gathered))}
-    if verify:
-        # every rank: its own bytes sit at its offset of the gathered image
-        own = all(torch.equal(g[rank * b.numel():(rank + 1) * b.numel()], b) for g, b in zip(gathered, be.buffers))
-        res["own_bytes_in_place"] = bool(own)
-        if rank == 0:
-            full = be.download_image(gathered, nsys_total)
-            res["ids_are_arange"] = bool((full.id == np.arange(nsys_total)).all())
-            res["full"] = full
+           "gathered_bytes": int(sum(b.numel() for b in be.buffers)) * world, "exchange": "gather to rank 0" if multi else "none"}
+    if verify and rank == 0:
+        # the bytes every rank sent are the bytes at its offset of the image: checksum of each slice against the sender's
+        got = torch.stack([buffer_checksums(list(g.split(b.numel()))) for g, b in zip(gathered, be.buffers)], dim=1)
+        res["checksums_match"] = bool(torch.equal(got.cpu(), sums.cpu()))
+        full = be.download_image(gathered, nsys_total)
+        res["ids_are_arange"] = bool((full.id == np.arange(nsys_total)).all())
+        res["full"] = full
     return res

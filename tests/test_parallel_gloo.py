@@ -189,7 +189,8 @@ def _sharded_worker(rank, world, port, nsys, nbod, q):
     cfg = S.config({"integrator": "mvs", "time_step": "0.01"})
     res = P.run_sharded(nsys, lambda lo, hi: full0.slice(lo, hi), lambda cap, n: _CpuStandIn(cap, n, nbod), cfg, 0.2,
                         dist=dist, rank=rank, world=world)
-    ok = res["own_bytes_in_place"] and res["stats"]["nsys"] == nsys and res["stats"]["n_inactive"] == nsys
+    ok = res["stats"]["nsys"] == nsys and res["stats"]["n_inactive"] == nsys and res["exchange"] == "gather to rank 0"
+    ok = ok and (("full" in res) == (rank == 0))          # only rank 0 receives the image
     ok = ok and res["stats"]["max_abs_dE_over_E"] < 1e-6
     if rank == 0:
         # the gathered image is the unsharded run
@@ -198,7 +199,7 @@ def _sharded_worker(rank, world, port, nsys, nbod, q):
             setattr(e, k, getattr(full0, k).copy())
         O.integrate(e, O.params("mvs", 0.2, time_step=0.01))
         got = res["full"]
-        ok = ok and res["ids_are_arange"] and np.array_equal(got.pos, e.pos) and np.array_equal(got.vel, e.vel)
+        ok = ok and res["checksums_match"] and res["ids_are_arange"] and np.array_equal(got.pos, e.pos) and np.array_equal(got.vel, e.vel)
         ok = ok and np.array_equal(got.time, e.time) and np.array_equal(got.state, e.state)
         ok = ok and np.array_equal(got.mass, e.mass)
     q.put((rank, bool(ok)))
@@ -208,8 +209,8 @@ def _sharded_worker(rank, world, port, nsys, nbod, q):
 @pytest.mark.parametrize("world,nsys", [(2, 200), (2, 64), (3, 330)])
 def test_sharded_run_harness_under_gloo(world, nsys, oracle):
     """bench.py --config c4 drives swarm_amd.parallel.run_sharded with the HIP backend; here the same function runs
-    with a CPU stand-in at world 2 and 3 (ragged shards, an empty rank at nsys=64): own bytes in place in the gathered
-    image, gathered ids = arange(nsys), gathered ensemble = the unsharded integration, statistics combined."""
+    with a CPU stand-in at world 2 and 3 (ragged shards, an empty rank at nsys=64): every rank's slice of the image gathered
+    on rank 0 has that rank's checksum, gathered ids = arange(nsys), gathered ensemble = the unsharded integration, statistics combined."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
