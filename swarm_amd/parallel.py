@@ -147,6 +147,11 @@ class HipShardBackend:
     def __init__(self, capacity, nsys, nbod, device, nbattr=1, nsattr=1):
         import torch
         from . import capi
+        if not torch.cuda.is_available():
+            # the PyTorch wheel and /opt/rocm each ship a libamdhip64.so.7; the first one loaded serves the whole
+            # process, and torch finds no GPU behind /opt/rocm's
+            raise RuntimeError("torch sees no GPU: in a process that uses both, import torch (and touch torch.cuda) "
+                               "BEFORE swarm_amd loads libswarm_hip.so")
         from .ensemble import DeviceEnsemble
         L = capi.lib
         self.capacity, self.nsys, self.nbod, self.nbattr, self.nsattr, self.device = capacity, nsys, nbod, nbattr, nsattr, device
