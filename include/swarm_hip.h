@@ -28,7 +28,11 @@ extern "C" {
 
 #define SWARM_HIP_CHUNK 64
 #define SWARM_HIP_MIN_NBOD 3
-#define SWARM_HIP_MAX_NBOD 10
+/* nbod 3 .. 10 run one lane per system or one lane per body (swarm_hip_launch_t::lane_mode); 11 .. 16 one lane per
+ * body only.  The reference instantiates 3 .. MAX_NBODIES (cmake/variables.cmake:55-72, default 6) and ships golden
+ * outputs up to nbod 13 (test/integrators/test.13.out.txt). */
+#define SWARM_HIP_MAX_NBOD 16
+#define SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM 10
 
 /* error codes */
 #define SWARM_HIP_OK 0
@@ -141,7 +145,14 @@ typedef struct swarm_hip_launch {
                                               evaluates them, `dfdt = (f*dgdt - 1)/g` with f and dgdt rounded to doubles
                                               next to 1 -- a deterministic error of ~1e-16/time_step per step.  1: the same
                                               expressions evaluated from f-1 and dgdt-1 (no cancellation); DESIGN.md 4 */
-    int32_t reserved0;
+    int32_t active_hint;                   /* number of ACTIVE systems if the caller knows it -- the result of its
+                                              swarm_hip_count_active after the previous launch of the attempt loop
+                                              (swarm/integrator.cpp:102-117) -- else 0.  When fewer systems are ACTIVE
+                                              than the ensemble holds, the choice between the two kernel layouts goes by
+                                              this number, and a lane-per-body launch first gathers the ACTIVE systems
+                                              into dense wavefronts (on the device, no synchronisation).  Results do
+                                              not depend on it; a hint below the true count leaves the surplus systems
+                                              ACTIVE for the next launch.  No reference key. */
     swarm_hip_log_t log;                   /* d_buf may be NULL: records are dropped     */
     /* optional per-system step counters, uint64 [nchunk*64] each, accumulated (+=) */
     uint64_t *d_steps_accepted;

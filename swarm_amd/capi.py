@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswa
 
 CHUNK = 64
 NOALLOC_MAX_NSYS = 1 << 26
-MIN_NBOD, MAX_NBOD = 3, 10
+MIN_NBOD, MAX_NBOD, MAX_NBOD_LANE_PER_SYSTEM = 3, 16, 10
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP, IRK2, IRK2_CPU = range(1, 12)
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT, MON_LOG_TRANSIT = 0, 1, 2, 3, 4
@@ -39,7 +39,7 @@ class LaunchStruct(C.Structure):
                 ("log_on_close_encounter", C.c_int32), ("verbose_on_close_encounter", C.c_int32),
                 ("close_approach", C.c_double), ("log_interval", C.c_double), ("rceh", C.c_double), ("irk2_method", C.c_int32), ("log_transits", C.c_int32), ("log_occultations", C.c_int32),
                 ("lane_mode", C.c_int32), ("log_transit_tol", C.c_double),
-                ("kepler_compensated", C.c_int32), ("reserved0", C.c_int32),
+                ("kepler_compensated", C.c_int32), ("active_hint", C.c_int32),
                 ("log", LogStruct),
                 ("d_steps_accepted", C.c_void_p), ("d_steps_attempted", C.c_void_p),
                 ("stream", C.c_void_p)]

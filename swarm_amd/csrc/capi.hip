@@ -66,6 +66,9 @@ static EnsView view_of(const swarm_hip_ensemble_t *ens) {
     v.body = ens->body;
     v.sysd = ens->sysd;
     v.sysi = ens->sysi;
+    v.alist = nullptr;
+    v.alist_n = nullptr;
+    v.alist_cap = 0;
     return v;
 }
 
@@ -127,6 +130,24 @@ __global__ void count_active_kernel(EnsView e, int32_t *out) {
     if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
     const unsigned long long m = __ballot(act);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// The ACTIVE systems of the ensemble gathered into a list (lane-per-body launches of a thinned-out ensemble,
+// prepare_body_launch): one ballot and one atomic per wavefront reserve the wave's run of slots; a wave's systems
+// stay in index order, the order of the waves' runs is whatever the atomics give -- a system's result does not depend
+// on which wavefront integrates it.  *count receives the number found; only the first `cap` are stored.
+__global__ __launch_bounds__(256) void active_list_kernel(EnsView e, int32_t *list, int32_t *count, int cap) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = false;
+    if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
+    const unsigned long long m = __ballot(act);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (act && at < cap) list[at] = gid;
 }
 
 // Two-pass count without atomics for swarm_hip_count_active_noalloc.  Pass 1: workgroup g counts the ACTIVE
@@ -503,6 +524,34 @@ static void launch_aos_convert(const swarm_hip_ensemble_t *ens, const AosStage &
 
 static int grid_for(int nsys, int block) { return (int)(((long long)nsys + block - 1) / block); }
 
+// launch.hpp.  The list lives in stream-ordered memory (hipMallocAsync / hipFreeAsync on the launch stream): no
+// synchronisation, and launches on different streams of one GPU do not share it.  Layout: int32 count at [0], the
+// list from [64] on.
+int prepare_body_launch(const LaunchCtx &c, int G, EnsView &view, int &grid) {
+    view = c.ens;
+    const int n = c.effective_nsys();
+    grid = (int)(((long long)n + G - 1) / G);
+    if (n == c.ens.nsys) return SWARM_HIP_OK;
+    int32_t *mem = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&mem, ((size_t)n + 64) * sizeof(int32_t), c.stream));
+    hipError_t err = hipMemsetAsync(mem, 0, sizeof(int32_t), c.stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(active_list_kernel, dim3(grid_for(c.ens.nsys, 256)), dim3(256), 0, c.stream, c.ens, mem + 64, mem, n);
+        err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+        (void)hipFreeAsync(mem, c.stream);
+        HIP_TRY(err);
+    }
+    view.alist = mem + 64;
+    view.alist_n = mem;
+    view.alist_cap = n;
+    return SWARM_HIP_OK;
+}
+void finish_body_launch(const LaunchCtx &c, const EnsView &view) {
+    if (view.alist_n) (void)hipFreeAsync(const_cast<int32_t *>(view.alist_n), c.stream);
+}
+
 } // namespace swh
 
 using namespace swh;
@@ -603,6 +652,11 @@ int swarm_hip_launch_integrator(const swarm_hip_ensemble_t *ens, const swarm_hip
         return SWARM_HIP_EINVAL;
     }
     c.lane_mode = a->lane_mode;
+    if (a->active_hint < 0) {
+        set_error("active_hint=%d must be >= 0 (0 = not known)", a->active_hint);
+        return SWARM_HIP_EINVAL;
+    }
+    c.active_hint = a->active_hint;
     c.stream = (hipStream_t)a->stream;
 
     switch (a->integrator) {

@@ -23,7 +23,28 @@ struct EnsView {
     double *body;
     double *sysd;
     int32_t *sysi;
+    // Active list (lane-per-body kernels only, NULL otherwise): the systems that were ACTIVE when the launch was
+    // prepared, gathered into alist[0 .. *alist_n) by active_list_kernel (capi.hip), so that a run whose ensemble has
+    // thinned out -- the tail of an adaptive or monitored run -- works on dense wavefronts.
+    const int32_t *alist;
+    const int32_t *alist_n; // device count of ACTIVE systems found; at most alist_cap of them are in the list
+    int alist_cap;
 };
+
+// Lane-per-body kernels: the system that slot `slot` of the launch works on (slot = workgroup * systems-per-wave +
+// group of the lane).  Without a list slot k is system k.  `lane_ok` = the lane belongs to a whole group of its wave.
+__device__ __forceinline__ bool body_slot_system(const EnsView &e, const bool lane_ok, const long long slot, int &sys) {
+    bool ok;
+    if (e.alist) {
+        const int n = *e.alist_n;
+        ok = lane_ok && slot < (long long)(n < e.alist_cap ? n : e.alist_cap);
+        sys = ok ? e.alist[slot] : 0;
+    } else {
+        ok = lane_ok && slot < (long long)e.nsys;
+        sys = ok ? (int)slot : 0;
+    }
+    return ok;
+}
 
 struct MonParams {
     int kind;

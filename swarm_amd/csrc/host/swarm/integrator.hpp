@@ -57,6 +57,7 @@ class integrator : public swarm::integrator {
 protected:
     swarm_hip_ensemble_t _dens; // device wave-chunk image, owned
     void *_stream;
+    int _active_count; // ACTIVE systems as counted after the last launch of the attempt loop; 0 = not known
     void release_device();
 
 public:

@@ -232,7 +232,7 @@ Pintegrator integrator::create(const config &cfg) {
 // ---- gpu::integrator -------------------------------------------------------------------------
 namespace gpu {
 
-integrator::integrator(const config &cfg) : swarm::integrator(cfg), _stream(0) { std::memset(&_dens, 0, sizeof(_dens)); }
+integrator::integrator(const config &cfg) : swarm::integrator(cfg), _stream(0), _active_count(0) { std::memset(&_dens, 0, sizeof(_dens)); }
 integrator::~integrator() { release_device(); }
 void integrator::release_device() {
     if (_dens.body) swarm_hip_free(_dens.body);
@@ -266,14 +266,17 @@ void integrator::download_ensemble() {
 }
 int integrator::core_integrate() {
     int attempts = 0;
+    _active_count = 0;
     for (int i = 0; i < _max_attempts; i++) {
-        launch_integrator();
+        launch_integrator(); // hands _active_count on as swarm_hip_launch_t::active_hint
         _logman->flush();
         attempts++;
         int32_t n = 0;
         hipErrCheck(swarm_hip_count_active(&_dens, _stream, &n));
         if (n == 0) break;
+        _active_count = n;
     }
+    _active_count = 0;
     return attempts;
 }
 void integrator::integrate() {
@@ -358,6 +361,7 @@ public:
         a.max_iterations = _max_iterations;
         a.log = _logman->get_gpulog();
         a.stream = _stream;
+        a.active_hint = _active_count;
         hipErrCheck(swarm_hip_launch_integrator(&_dens, &a));
     }
 };

@@ -418,8 +418,8 @@ static int launch_n(const LaunchCtx &c) {
 // nsys ~ 8k for nbod 3, 24-36k for nbod 4..10; at 4096 systems the lane-per-body kernel is 1.5x (nbod 4) to 3.9x
 // (nbod 10) faster.  Limits sit at the last grid point where it still wins.
 static bool small_mvs_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 6144, 20480, 24576, 24576, 24576, 32768, 24576, 24576};
-    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+    static const int limit[SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM + 1] = {0, 0, 0, 6144, 20480, 24576, 24576, 24576, 32768, 24576, 24576};
+    return within_limit(c, limit);
 }
 
 // euler, midpoint, verlet, hermite_prop: one lane per body (kernels_prop_body.hip) for small ensembles.  Measured
@@ -427,38 +427,41 @@ static bool small_mvs_ensemble(const LaunchCtx &c) {
 // systems (one wavefront per SIMD at most), the lane-per-body kernels win below ~16384 systems from nbod 4 on (nbod 10,
 // 2048 systems: 4-5x); at nbod 3 only hermite_prop gains anything; verlet, whose lanes also add up the system's
 // time-step sum, from nbod 5 on.
-static bool prop_body_selected(const LaunchCtx &c, int integrator) {
-    if (body_monitor_of(c.mp) == MONB_NONE) return false;
-    if (c.lane_mode != 0) return c.lane_mode == 2;
-    const int nbod = c.ens.nbod, nsys = c.ens.nsys;
+static bool prop_prefers_body(const LaunchCtx &c, int integrator) {
+    const int nbod = c.ens.nbod, nsys = c.effective_nsys();
     if (integrator == SWARM_HIP_VERLET) return nbod >= 5 && nsys <= (nbod < 8 ? 8192 : 16384);
     if (nbod == 3) return integrator == SWARM_HIP_HERMITE_PROP && nsys <= 8192;
     return nsys <= 16384;
 }
 
 int launch_generic(const LaunchCtx &c, int integrator) {
+    // small ensembles with nothing to monitor, or a monitor that does not print: one lane per body
+    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
+    int layout = 0;
     switch (integrator) {
-    case SWARM_HIP_MVS: {
-        // small ensembles with nothing to monitor, or stop_on_ejection without printing
-        const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
-        if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_mvs_ensemble(c)))) return launch_mvs_body(c);
+    case SWARM_HIP_MVS: layout = choose_layout(c, body_ok, small_mvs_ensemble(c)); break;
+    case SWARM_HIP_EULER:
+    case SWARM_HIP_VERLET:
+    case SWARM_HIP_MIDPOINT:
+    case SWARM_HIP_HERMITE_PROP: layout = choose_layout(c, body_ok, prop_prefers_body(c, integrator)); break;
+    default: break;
     }
+    if (layout < 0) return layout;
+    if (layout == 1) return integrator == SWARM_HIP_MVS ? launch_mvs_body(c) : launch_prop_body(c, integrator);
+    switch (integrator) {
+    case SWARM_HIP_MVS:
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
         break;
     case SWARM_HIP_EULER:
-        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_EULER>(c)));
         break;
     case SWARM_HIP_VERLET:
-        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_VERLET>(c)));
         break;
     case SWARM_HIP_MIDPOINT:
-        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MIDPOINT>(c)));
         break;
     case SWARM_HIP_HERMITE_PROP:
-        if (prop_body_selected(c, integrator)) return launch_prop_body(c, integrator);
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_HERMITE_PROP>(c)));
         break;
     default:

@@ -220,16 +220,17 @@ static int launch_n(const LaunchCtx &c) {
 // nbod 3..7 and 9, 36k for nbod 8, 45k for nbod 10) the lane-per-system kernel's throughput wins.  Limits sit at the
 // last grid point where the lane-per-body kernel still wins.
 static bool small_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 20480, 24576, 24576, 24576, 32768, 24576, 40960};
-    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+    static const int limit[SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM + 1] = {0, 0, 0, 16384, 20480, 24576, 24576, 24576, 32768, 24576, 40960};
+    return within_limit(c, limit);
 }
 
 int launch_hermite(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, with stop_on_ejection or the ejection-or-close-encounter composite
     // (deactivation and/or snapshot records, no printf) or with log_time_interval: one lane per body (kernels_hermite_body.hip), each lane testing its own planet and
     // writing its own body's part of a record
-    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
-    if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_ensemble(c)))) return launch_hermite_body(c, adaptive);
+    const int layout = choose_layout(c, body_monitor_of(c.mp) != MONB_NONE, small_ensemble(c));
+    if (layout < 0) return layout;
+    if (layout == 1) return launch_hermite_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {

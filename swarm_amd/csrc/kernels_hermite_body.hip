@@ -29,9 +29,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM;
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
-    const long long sys_ll = (long long)blockIdx.x * G + g;
-    const bool valid = lane < G * N && sys_ll < e.nsys;
-    const int sys = valid ? (int)sys_ll : 0;
+    int sys;
+    const bool valid = body_slot_system(e, lane < G * N, (long long)blockIdx.x * G + g, sys);
     const int base = g * N; // first lane of my system
 
     // own body, the partners' masses, the system's time and state (every lane of a group holds a copy)
@@ -202,10 +201,12 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
-    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    EnsView view;
+    int grid;
+    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
     const int monb = body_monitor_of(c.mp);
 #define SWH_LAUNCH_BODY(M, AD)                                                                                         \
-    hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
     if (adaptive) {
         if (monb == MONB_EJECTION)
             SWH_LAUNCH_BODY(MONB_EJECTION, true);
@@ -226,11 +227,12 @@ static int launch_body_n(const LaunchCtx &c, bool adaptive) {
             SWH_LAUNCH_BODY(MONB_OFF, false);
     }
 #undef SWH_LAUNCH_BODY
+    finish_body_launch(c, view);
     return check_launch("hermite (lane per body) kernel launch");
 }
 
 int launch_hermite_body(const LaunchCtx &c, bool adaptive) {
-    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N>(c, adaptive)));
+    SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N>(c, adaptive)));
     return SWARM_HIP_OK;
 }
 

@@ -220,14 +220,16 @@ int SWH_IRK2_CAT(launch_irk2_s, SWH_IRK2_NS)(const LaunchCtx &c, bool cpu_rules)
 // ensemble size (65536 systems: 3x at nbod 4 ... 5x at nbod 10; 2048 systems: 7x ... 20x); at nbod 3 it wins while
 // the ensemble is too small to fill the chip with wavefronts of whole systems (crossover ~ 55k systems).
 // WORKLOAD=irk2 tools/lane_sweep.sh, profiles/r2/irk2_lane_sweep.txt.
-static bool irk2_prefers_body(const LaunchCtx &c) { return c.ens.nbod >= 4 || c.ens.nsys <= 49152; }
+static bool irk2_prefers_body(const LaunchCtx &c) { return c.ens.nbod >= 4 || c.effective_nsys() <= 49152; }
 
 int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
     if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
         if (int rc = mce_check_attributes(c)) return rc;
     // one lane per body (kernels_irk2_body.hip) with nothing to monitor, or stop_on_ejection without printing
     const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT && body_monitor_of(c.mp) != MONB_NONE;
-    if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && irk2_prefers_body(c)))) return launch_irk2_body(c, method, cpu_rules);
+    const int layout = choose_layout(c, body_ok, irk2_prefers_body(c));
+    if (layout < 0) return layout;
+    if (layout == 1) return launch_irk2_body(c, method, cpu_rules);
     switch (method) {
     case 2: return launch_irk2_s2(c, cpu_rules);
     case 4: return launch_irk2_s4(c, cpu_rules);

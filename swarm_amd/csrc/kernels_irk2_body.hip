@@ -31,9 +31,8 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
-    const long long sys_ll = (long long)blockIdx.x * G + g;
-    const bool valid = lane < G * N && sys_ll < e.nsys;
-    const int sys = valid ? (int)sys_ll : 0;
+    int sys;
+    const bool valid = body_slot_system(e, lane < G * N, (long long)blockIdx.x * G + g, sys);
     const int base = valid ? g * N : 0; // first lane of my system (idle lanes read system 0 of the wave)
     const unsigned long long group_mask = ((1ull << N) - 1) << base;
 
@@ -245,9 +244,11 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
     const double uround = cpu_rules ? 1e-16 : 2.221e-16;
     const int nitmax = cpu_rules ? 50 : 100;
     constexpr int G = W / N;
-    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    EnsView view;
+    int grid;
+    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
 #define SWH_LAUNCH_BODY(M)                                                                                              \
-    hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt, \
+    hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt, \
                        uround, nitmax, cpu_rules)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
@@ -256,14 +257,15 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
+    finish_body_launch(c, view);
     return check_launch("irk2 (lane per body) kernel launch");
 }
 
 int launch_irk2_body(const LaunchCtx &c, int method, bool cpu_rules) {
     switch (method) {
-    case 2: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_ns<N, 2>(c, cpu_rules))); break;
-    case 4: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_ns<N, 4>(c, cpu_rules))); break;
-    case 6: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_ns<N, 6>(c, cpu_rules))); break;
+    case 2: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_ns<N, 2>(c, cpu_rules))); break;
+    case 4: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_ns<N, 4>(c, cpu_rules))); break;
+    case 6: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_ns<N, 6>(c, cpu_rules))); break;
     default:
         set_error("irk2: method=%d, the number of stages must be 2, 4 or 6 (irk2_integrator.hpp:291,322,391)", method);
         return SWARM_HIP_EINVAL;

@@ -28,9 +28,8 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
-    const long long sys_ll = (long long)blockIdx.x * G + g;
-    const bool valid = lane < G * N && sys_ll < e.nsys;
-    const int sys = valid ? (int)sys_ll : 0;
+    int sys;
+    const bool valid = body_slot_system(e, lane < G * N, (long long)blockIdx.x * G + g, sys);
     const int base = valid ? g * N : 0;      // first lane of my system (idle lanes read system 0 of the wave)
     const unsigned long long group_mask = ((1ull << N) - 1) << base;
 
@@ -254,9 +253,11 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 template <int N>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
-    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    EnsView view;
+    int grid;
+    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
 #define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
@@ -264,11 +265,12 @@ static int launch_body_n(const LaunchCtx &c) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
+    finish_body_launch(c, view);
     return check_launch("mvs (lane per body) kernel launch");
 }
 
 int launch_mvs_body(const LaunchCtx &c) {
-    SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N>(c)));
+    SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N>(c)));
     return SWARM_HIP_OK;
 }
 

@@ -25,9 +25,8 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
-    const long long sys_ll = (long long)blockIdx.x * G + g;
-    const bool valid = lane < G * N && sys_ll < e.nsys;
-    const int sys = valid ? (int)sys_ll : 0;
+    int sys;
+    const bool valid = body_slot_system(e, lane < G * N, (long long)blockIdx.x * G + g, sys);
     const int base = valid ? g * N : 0; // first lane of my system (idle lanes read system 0 of the wave)
     const unsigned long long group_mask = ((1ull << N) - 1) << base;
 
@@ -281,9 +280,11 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
 template <int N, int KIND>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
-    const int grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    EnsView view;
+    int grid;
+    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
 #define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(grid), dim3(W), 0, c.stream, c.ens, c.ip, c.mp, c.lg, c.cnt)
+    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
@@ -291,15 +292,16 @@ static int launch_body_n(const LaunchCtx &c) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
+    finish_body_launch(c, view);
     return check_launch("propagator (lane per body) kernel launch");
 }
 
 int launch_prop_body(const LaunchCtx &c, int integrator) {
     switch (integrator) {
-    case SWARM_HIP_EULER: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_EULER>(c))); break;
-    case SWARM_HIP_MIDPOINT: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_MIDPOINT>(c))); break;
-    case SWARM_HIP_HERMITE_PROP: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_HERMITE_PROP>(c))); break;
-    case SWARM_HIP_VERLET: SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_VERLET>(c))); break;
+    case SWARM_HIP_EULER: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_EULER>(c))); break;
+    case SWARM_HIP_MIDPOINT: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_MIDPOINT>(c))); break;
+    case SWARM_HIP_HERMITE_PROP: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_HERMITE_PROP>(c))); break;
+    case SWARM_HIP_VERLET: SWH_DISPATCH_NBOD_BODY(c.ens.nbod, return (launch_body_n<N, SWARM_HIP_VERLET>(c))); break;
     default: set_error("no lane-per-body kernel for propagator id %d", integrator); return SWARM_HIP_EINVAL;
     }
     return SWARM_HIP_OK;

@@ -201,14 +201,15 @@ static int launch_n(const LaunchCtx &c) {
 // with WORKLOAD=c3 tools/lane_sweep.sh (profiles/r2/rkck_lane_sweep.txt); at 2048 systems the lane-per-body kernel
 // is 1.2x (nbod 3) to 15x (nbod 10) faster.
 static bool small_rkck_ensemble(const LaunchCtx &c) {
-    static const int limit[SWARM_HIP_MAX_NBOD + 1] = {0, 0, 0, 16384, 32768, 24576, 20480, 40960, 49152, INT_MAX, INT_MAX};
-    return c.ens.nbod <= SWARM_HIP_MAX_NBOD && c.ens.nsys <= limit[c.ens.nbod];
+    static const int limit[SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM + 1] = {0, 0, 0, 16384, 32768, 24576, 20480, 40960, 49152, INT_MAX, INT_MAX};
+    return within_limit(c, limit);
 }
 
 int launch_rkck(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, or stop_on_ejection without printing
-    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
-    if (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && small_rkck_ensemble(c)))) return launch_rkck_body(c, adaptive);
+    const int layout = choose_layout(c, body_monitor_of(c.mp) != MONB_NONE, small_rkck_ensemble(c));
+    if (layout < 0) return layout;
+    if (layout == 1) return launch_rkck_body(c, adaptive);
     if (adaptive) {
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, true>(c)));
     } else {

@@ -15,8 +15,19 @@ struct LaunchCtx {
     int block;      // threads per workgroup
     int grid;       // workgroups
     int lane_mode;  // swarm_hip_launch_t::lane_mode
+    int active_hint; // swarm_hip_launch_t::active_hint: ACTIVE systems as last counted by the caller, 0 = not known
     hipStream_t stream;
+    // the number of systems that the choice between the two kernel layouts goes by: the ACTIVE ones where known
+    int effective_nsys() const { return (active_hint > 0 && active_hint < ens.nsys) ? active_hint : ens.nsys; }
 };
+
+// Lane-per-body launches (capi.hip).  prepare: `view` = the ensemble as the kernel sees it and `grid` = its workgroups
+// (one wavefront of G systems each).  When the caller's hint says that fewer systems are ACTIVE than the ensemble
+// holds, the ACTIVE ones are first gathered into a list on the device (stream-ordered allocation, one small kernel) and
+// the kernel walks that list: dense wavefronts for the tail of an adaptive or monitored run.  finish: gives the list
+// back (stream-ordered), after the kernel has been enqueued.
+int prepare_body_launch(const LaunchCtx &c, int G, EnsView &view, int &grid);
+void finish_body_launch(const LaunchCtx &c, const EnsView &view);
 
 void set_error(const char *fmt, ...);
 
@@ -41,6 +52,7 @@ int launch_irk2_body(const LaunchCtx &c, int method, bool cpu_rules); // one lan
 #define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
     if (nbod == SWH_DISPATCH_ONLY) { constexpr int N = SWH_DISPATCH_ONLY; CALL; } \
     else { set_error("experiment build: nbod=%d only", SWH_DISPATCH_ONLY); return SWARM_HIP_EINVAL; }
+#define SWH_DISPATCH_NBOD_BODY(nbod, CALL) SWH_DISPATCH_NBOD(nbod, CALL)
 #else
 #define SWH_DISPATCH_NBOD(nbod, CALL)                                      \
     switch (nbod) {                                                        \
@@ -53,10 +65,54 @@ int launch_irk2_body(const LaunchCtx &c, int method, bool cpu_rules); // one lan
     case 9: { constexpr int N = 9; CALL; } break;                          \
     case 10: { constexpr int N = 10; CALL; } break;                        \
     default:                                                               \
+        set_error("nbod=%d outside [%d,%d] (one lane per system)", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM); \
+        return SWARM_HIP_EUNSUPPORTED;                                     \
+    }
+// the lane-per-body kernels keep one body per lane whatever nbod is: 3 .. SWARM_HIP_MAX_NBOD (floor(64/nbod) systems
+// per wavefront); the reference's ctest runs nbod = 3 .. MAX_NBODIES and ships goldens up to 13
+#define SWH_DISPATCH_NBOD_BODY(nbod, CALL)                                 \
+    switch (nbod) {                                                        \
+    case 3: { constexpr int N = 3; CALL; } break;                          \
+    case 4: { constexpr int N = 4; CALL; } break;                          \
+    case 5: { constexpr int N = 5; CALL; } break;                          \
+    case 6: { constexpr int N = 6; CALL; } break;                          \
+    case 7: { constexpr int N = 7; CALL; } break;                          \
+    case 8: { constexpr int N = 8; CALL; } break;                          \
+    case 9: { constexpr int N = 9; CALL; } break;                          \
+    case 10: { constexpr int N = 10; CALL; } break;                        \
+    case 11: { constexpr int N = 11; CALL; } break;                        \
+    case 12: { constexpr int N = 12; CALL; } break;                        \
+    case 13: { constexpr int N = 13; CALL; } break;                        \
+    case 14: { constexpr int N = 14; CALL; } break;                        \
+    case 15: { constexpr int N = 15; CALL; } break;                        \
+    case 16: { constexpr int N = 16; CALL; } break;                        \
+    default:                                                               \
         set_error("nbod=%d outside [%d,%d]", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD); \
         return SWARM_HIP_EINVAL;                                           \
     }
 #endif
+
+// nbod beyond the lane-per-system kernels' range runs one lane per body whatever the ensemble size
+inline bool body_only_nbod(const LaunchCtx &c) { return c.ens.nbod > SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM; }
+
+// The layout a launch takes: 1 = one lane per body, 0 = one lane per system, < 0 = error (set).  `body_ok`: the
+// lane-per-body kernel serves the bound monitor; `prefers_body`: the integrator's measured crossover says so for this
+// many (ACTIVE) systems.  lane_mode 1 / 2 force a layout where both exist.
+inline int choose_layout(const LaunchCtx &c, bool body_ok, bool prefers_body) {
+    if (body_only_nbod(c)) {
+        if (body_ok) return 1;
+        set_error("nbod=%d runs one lane per body (nbod > %d), which serves the no-op monitor, stop_on_ejection, "
+                  "log_time_interval and the ejection-or-close-encounter composite without verbose_on_* keys; "
+                  "mce_stat, log_transit and the printing monitors stop at nbod %d",
+                  c.ens.nbod, SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM, SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM);
+        return SWARM_HIP_EUNSUPPORTED;
+    }
+    return (body_ok && (c.lane_mode == 2 || (c.lane_mode == 0 && prefers_body))) ? 1 : 0;
+}
+// crossover tables hold one limit per nbod 0 .. SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM
+inline bool within_limit(const LaunchCtx &c, const int (&limit)[SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM + 1]) {
+    return c.ens.nbod <= SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM && c.effective_nsys() <= limit[c.ens.nbod];
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

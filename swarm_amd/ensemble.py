@@ -169,6 +169,9 @@ class DeviceEnsemble:
         else:
             self._own = []
         self.c = capi.EnsembleStruct(self.nsys, self.nbod, self.nbattr, self.nsattr, *pointers)
+        # ACTIVE systems as last counted (count_active), None when something may have changed the states since:
+        # GpuIntegrator hands it to the next launch as swarm_hip_launch_t::active_hint
+        self.last_active_count = None
 
     @property
     def ref(self):
@@ -180,6 +183,7 @@ class DeviceEnsemble:
                                                   h.body_attr, h.sys_attr)]
         assert arrs[4].dtype == np.int32 and arrs[5].dtype == np.int32
         capi.check(capi.lib.swarm_hip_upload_aos(self.ref, *[_ptr(a) for a in arrs]))
+        self.last_active_count = None
 
     def download(self, h=None):
         h = h if h is not None else HostEnsemble(self.nsys, self.nbod, self.nbattr, self.nsattr)
@@ -191,10 +195,12 @@ class DeviceEnsemble:
     def count_active(self, stream=None):
         n = C.c_int32()
         capi.check(capi.lib.swarm_hip_count_active(self.ref, stream, C.byref(n)))
+        self.last_active_count = n.value
         return n.value
 
     def reactivate(self, stream=None):
         capi.check(capi.lib.swarm_hip_reactivate(self.ref, stream))
+        self.last_active_count = None
 
     def total_energy(self, stream=None):
         n = capi.lib.swarm_hip_nchunk(self.nsys) * capi.CHUNK

@@ -269,6 +269,7 @@ class GpuIntegrator(Integrator):
         if self.int_id == capi.MVS:                                   # not a reference key, see include/swarm_hip.h
             a.kepler_compensated = int(cfg.optional("kepler_compensated", 0))
         a.lane_mode = cfg.optional("lane_mode", 0)                     # not a reference key: 0 auto, 1 per system, 2 per body
+        self.use_active_hint = bool(cfg.optional("active_hint", 1))   # not a reference key: 0 = never pass the count on
         self.args = a
         self.steps_accepted = None
         self.steps_attempted = None
@@ -327,12 +328,16 @@ class GpuIntegrator(Integrator):
         a.d_steps_accepted = self.steps_accepted.ptr if self.steps_accepted else None
         a.d_steps_attempted = self.steps_attempted.ptr if self.steps_attempted else None
         a.stream = self.stream
+        # the count the attempt loop made after the previous launch (integrator.cpp:113), if nothing has touched the
+        # states since: lets the library pick the kernel layout by ACTIVE systems and pack them into dense wavefronts
+        a.active_hint = (self._dens.last_active_count or 0) if self.use_active_hint else 0
         if self.name in ("hermite", "irk2"):
             a.monitor = capi.MON_MCE_STAT if self._dens.nbattr >= 3 else capi.MON_EJECTION
             if a.monitor == capi.MON_MCE_STAT and "nbod" in self.cfg and int(self.cfg["nbod"]) != self._dens.nbod:
                 raise runtime_error("mce_stat: nbod=%s in the configuration but the ensemble has %d bodies"
                                     % (self.cfg["nbod"], self._dens.nbod))
         capi.check(capi.lib.swarm_hip_launch_integrator(self._dens.ref, C.byref(a)))
+        self._dens.last_active_count = None     # the launch changes states
 
     def core_integrate(self):
         """The device-resident part of integrate(): attempt loop without host<->device copies."""

@@ -154,7 +154,7 @@ def test_printf_records_sort_first_and_query_prints_them_with_T_minus_one(tmp_pa
 
 # ---------------------------------------------------------------- GPU side
 CTEST = [("Hermite", 1e-8), ("Hermite_Adaptive", 1e-8), ("RKCK_Adaptive", 1e-8), ("RKCK_Fixed", 1e-8), ("MVS", 1e-8),
-         ("irk2", 1e-8)]
+         ("irk2", 1e-8), ("Euler", 1e-8), ("Midpoint", 1e-8), ("Verlet", 1e-8)]   # Euler/Midpoint 10^5, Verlet 10^6 steps
 # MVS.cfg as shipped: nbod 3, 4 meet 1e-8; nbod 5, 6 sit on the deterministic rounding offset of the reference's own
 # f/g formula (1.46e-8, 3.21e-8 in velocity; tests/test_gpu_integrators.py::test_mvs_ctest_configuration_and_the_
 # fg_rounding_floor), which the CPU restatement of that formula shares to 4e-12.
@@ -313,7 +313,7 @@ def test_reference_bdb_script_through_the_gpu_path(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])     # every golden pair the reference ships
 def test_reference_hermite_cpu_cfg_reproduces_goldens(nbod):
     """test/integrators/Hermite_CPU.cfg is the configuration the golden outputs were generated with
     (test/integrators/generate.sh).  Run unchanged (integrator=hermite_cpu, nogpu=1) it must reproduce

@@ -82,6 +82,9 @@ def test_integrator_vs_oracle(gpu, oracle, name, nbod):
     ("mvs", {"time_step": "0.0003"}),
     ("irk2", {"time_step": "0.01", "nbod": "3"}),            # test/integrators/irk2.cfg
     ("irk2_cpu", {"time_step": "0.0001", "nogpu": "1"}),     # irk2_cpu.cfg has 1e-6 (10^6 steps); same bar
+    ("euler", {"time_step": "0.00001", "log_interval": "1"}),             # test/integrators/Euler.cfg as shipped
+    ("midpoint", {"time_step": "0.00001"}),                               # Midpoint.cfg
+    ("verlet", {"max_timestep": "0.000001", "timestep_scale": "1.0"}),    # Verlet.cfg: 10^6 steps per system
 ])
 @pytest.mark.parametrize("nbod", [3, 6])
 def test_reference_ctest_scenarios(gpu, oracle, name, cfg, nbod):

@@ -1,0 +1,130 @@
+"""nbod 11 .. 16: one lane per body only (SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM = 10 < nbod <= SWARM_HIP_MAX_NBOD).
+The reference instantiates nbod = 3 .. MAX_NBODIES (cmake/variables.cmake:55-72), its ctest loops over that range
+(cmake/test_integrators.cmake:33-39) and it ships golden pairs up to test.13.{in,out}.txt.  Bars: the goldens at the
+ctest's 1e-8, the oracle at north_star's 1e-10 with bit-exact times, states and step counts of fixed-step integrators."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, perturbed, rel_diff, to_host
+from test_gpu_integrators import CASES, run_gpu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.mark.parametrize("nbod", [11, 12, 13])
+def test_hermite_vs_reference_golden_files_nbod_11_13(gpu, oracle, nbod):
+    """Hermite.cfg (time_step=0.01) vs test.N.out.txt at 1e-8, and vs the oracle's hermite / hermite_cpu at 1e-10"""
+    S, O = gpu, oracle
+    e = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
+    ref = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.out.txt" % nbod))
+    h = to_host(S, e)
+    run_gpu(S, h, "hermite", {"time_step": "0.01"}, 1.0, counters=False)
+    pd = np.sqrt(((h.pos - ref.pos) ** 2).sum(-1)).max()
+    vd = np.sqrt(((h.vel - ref.vel) ** 2).sum(-1)).max()
+    assert pd < 1e-8 and vd < 1e-8, (pd, vd)
+    assert (h.state == ref.state).all() and (h.id == ref.id).all()
+    for form in ("hermite", "hermite_cpu"):
+        o = e.clone()
+        O.integrate(o, O.params(form, 1.0, time_step=0.01))
+        assert rel_diff(h.pos[:, 1:], o.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], o.vel[:, 1:]) < TOL
+        assert np.abs(h.pos[:, 0] - o.pos[:, 0]).max() < TOL and np.abs(h.vel[:, 0] - o.vel[:, 0]).max() < TOL
+        assert (h.time == o.time).all() and (h.state == o.state).all()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("nbod", [11, 13, 16])
+def test_integrator_vs_oracle_nbod_11_16(gpu, oracle, name, nbod):
+    """every integrator on a ragged ensemble (37 systems: 5 or 4 per wavefront, a last wavefront of 2 or 1)"""
+    S, O = gpu, oracle
+    cfg, okw, T = CASES[name]
+    T = 0.5
+    e = perturbed(O, 37, nbod, seed=nbod + 20)
+    e.time[::5] = 0.125
+    e.state[3::11] = O.DISABLED
+    h = to_host(S, e)
+    integ = run_gpu(S, h, name, cfg, T)
+    acc, att = O.integrate(e, O.params(name, T, **okw), threads=4, counters=True)
+    assert (h.state == e.state).all() and (h.id == e.id).all()
+    assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < TOL, rel_diff(h.pos[:, 1:], e.pos[:, 1:])
+    assert rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL
+    assert np.abs(h.pos[:, 0] - e.pos[:, 0]).max() < TOL and np.abs(h.vel[:, 0] - e.vel[:, 0]).max() < TOL
+    gacc, gatt = integ.step_counts()
+    if name in ("euler", "midpoint", "mvs", "rkck_fixed", "hermite_prop", "irk2", "irk2_cpu"):
+        assert (gacc == acc.astype(np.uint64)).all() and (gatt == att.astype(np.uint64)).all()
+        assert (h.time == e.time).all()
+    else:
+        assert np.abs(gacc.astype(np.int64) - acc).max() <= 1
+        np.testing.assert_allclose(h.time, e.time, rtol=1e-12)
+
+
+@pytest.mark.parametrize("nbod", [12, 16])
+def test_monitors_nbod_above_10(gpu, oracle, nbod):
+    """stop_on_ejection (deactivate + log) and log_time_interval beyond nbod 10: stop flags, stop times and the
+    records' bytes against the oracle"""
+    S, O = gpu, oracle
+    # every third system: the outermost planet just inside rmax, moving straight out -- it crosses rmax at t ~ 1; the
+    # others stay on their circles
+    e = perturbed(O, 23, nbod, seed=3, amp=1e-4)
+    r0 = 10 * 1.4 ** (nbod - 2)
+    r = e.pos[::3, nbod - 1].copy()
+    e.pos[::3, nbod - 1] = r * 1.045
+    e.vel[::3, nbod - 1] = r / np.sqrt((r ** 2).sum(-1))[:, None] * (0.005 * r0)
+    h = to_host(S, e)
+    rmax = 1.05 * r0
+    cfg = {"integrator": "hermite", "time_step": "0.01", "deactivate_on_ejection": "1", "log_on_ejection": "1",
+           "rmax": repr(rmax)}
+    integ = S.Integrator.create(S.config(cfg))
+    lm = S.LogManager(1 << 20, "host")
+    integ.set_log_manager(lm)
+    integ.set_ensemble(h)
+    integ.set_destination_time(3.0)
+    integ.integrate()
+    olog = O.Log(1 << 20)
+    O.integrate(e, O.params("hermite", 3.0, time_step=0.01), O.monitor(rmax=rmax, deactivate_on_ejection=1, log_on_ejection=1),
+                olog)
+    assert (h.state == e.state).all() and (h.state == O.DISABLED).sum() == len(range(0, 23, 3))
+    assert (h.time == e.time).all() and 0.5 < h.time[0] < 2.0 and h.time[1] == 3.0
+    mine = sorted(O.parse_log(bytes(lm.host)), key=lambda r: r["sys"])
+    theirs = sorted(olog.records(), key=lambda r: r["sys"])
+    assert len(mine) == len(theirs) == (h.state == O.DISABLED).sum()
+    for a, b in zip(mine, theirs):
+        assert a["sys"] == b["sys"] and a["time"] == b["time"] and a["state"] == b["state"] and a["nbod"] == nbod
+        assert rel_diff(a["bodies"][1:, :3], b["bodies"][1:, :3]) < TOL
+    # log_time_interval: record counts per system
+    e = perturbed(O, 9, nbod, seed=4)
+    h = to_host(S, e)
+    integ = S.Integrator.create(S.config({"integrator": "hermite_adap_log", "time_step_factor": "0.02",
+                                          "min_time_step": "1e-7", "log_interval": "0.1"}))
+    lm = S.LogManager(4 << 20, "host")
+    integ.set_log_manager(lm)
+    integ.set_ensemble(h)
+    integ.set_destination_time(0.5)
+    integ.integrate()
+    olog = O.Log(4 << 20)
+    O.integrate(e, O.params("hermite_adap", 0.5, time_step_factor=0.02, min_time_step=1e-7),
+                O.monitor(kind=O.MON_LOG_INTERVAL, log_interval=0.1), olog)
+    mine, theirs = O.parse_log(bytes(lm.host)), olog.records()
+    assert len(mine) == len(theirs) and lm.dropped == 0
+    assert np.array_equal(np.bincount([r["sys"] for r in mine], minlength=9), np.bincount([r["sys"] for r in theirs], minlength=9))
+    assert len(bytes(lm.host)) == len(mine) * ((32 + 64 * nbod + 15) // 16 * 16)
+
+
+def test_what_stops_at_nbod_10_says_so(gpu, oracle):
+    """one lane per system, the printing monitors and mce_stat stop at nbod 10: a clear error, not a fallback"""
+    S, O = gpu, oracle
+    h = to_host(S, perturbed(O, 8, 11, seed=1))
+    for extra in ({"lane_mode": "1"}, {"verbose_on_ejection": "1", "rmax": "5"}):
+        integ = S.Integrator.create(S.config(dict({"integrator": "hermite", "time_step": "0.01"}, **extra)))
+        integ.set_ensemble(h.clone())
+        integ.set_destination_time(0.1)
+        if "lane_mode" in extra:
+            integ.integrate()          # lane_mode=1 cannot be honoured beyond nbod 10: one lane per body is what runs
+            continue
+        with pytest.raises(S.capi.SwarmHipError, match="one lane per body"):
+            integ.integrate()
+    h17 = S.HostEnsemble(4, 17)
+    with pytest.raises(S.capi.SwarmHipError, match="nbod"):
+        S.DeviceEnsemble(4, 17).upload(h17)

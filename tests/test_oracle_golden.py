@@ -49,6 +49,7 @@ CFGS = {
     "euler": dict(time_step=1e-5),
     "midpoint": dict(time_step=1e-5),
     "hermite_prop": dict(time_step=0.01),     # samples/Hermite_Prop.cfg family
+    "verlet": dict(max_timestep=1e-6, timestep_scale=1.0),     # test/integrators/Verlet.cfg: 10^6 steps per system
 }
 
 
@@ -58,7 +59,7 @@ def test_gpu_form_restatements_meet_reference_ctest_bar(oracle, name, nbod):
     O = oracle
     e = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.in.txt" % nbod))
     ref = O.load_text(os.path.join(GOLDEN, "integrators", "test.%d.out.txt" % nbod))
-    O.integrate(e, O.params(name, 1.0, **CFGS[name]), threads=4)
+    O.integrate(e, O.params(name, 1.0, **CFGS[name]), threads=8 if name == "verlet" else 4)
     pd, vd, td = O.compare(e, ref)
     assert pd < 1e-8 and vd < 1e-8 and td < 1e-8, (pd, vd, td)
     assert (e.state == O.INACTIVE).all()
