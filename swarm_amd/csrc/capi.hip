@@ -135,19 +135,33 @@ __global__ void count_active_kernel(EnsView e, int32_t *out) {
 // The ACTIVE systems of the ensemble gathered into a list (lane-per-body launches of a thinned-out ensemble,
 // prepare_body_launch): one ballot and one atomic per wavefront reserve the wave's run of slots; a wave's systems
 // stay in index order, the order of the waves' runs is whatever the atomics give -- a system's result does not depend
-// on which wavefront integrates it.  *count receives the number found; only the first `cap` are stored.
-__global__ __launch_bounds__(256) void active_list_kernel(EnsView e, int32_t *list, int32_t *count, int cap) {
+// on which wavefront integrates it.  count[0] receives the number found; only the first `cap` are stored.  With
+// `rest` the systems that are NOT ACTIVE are listed as well (count[1], room for all of them): hermite_adap and rkck
+// call their monitor once before the step loop for every system, whatever its state (hermite_adap.hpp:130,
+// rkck_integrator.hpp:140), and a second launch over that list makes those calls.
+__global__ __launch_bounds__(256) void active_list_kernel(EnsView e, int32_t *list, int32_t *count, int cap, int32_t *rest) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = gid < e.nsys;
     bool act = false;
-    if (gid < e.nsys) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
-    const unsigned long long m = __ballot(act);
-    if (m == 0) return;
+    if (in) act = e.sysi[(size_t)(gid / W) * 2 * W + gid % W] == SWARM_HIP_ACTIVE;
     const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0);
-    const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (act && at < cap) list[at] = gid;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m = __ballot(act);
+    if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, __popcll(m));
+        base = __shfl(base, 0);
+        const int at = base + __popcll(m & below);
+        if (act && at < cap) list[at] = gid;
+    }
+    if (!rest) return;
+    const unsigned long long r = __ballot(in && !act);
+    if (r) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count + 1, __popcll(r));
+        base = __shfl(base, 0);
+        if (in && !act) rest[base + __popcll(r & below)] = gid;
+    }
 }
 
 // Two-pass count without atomics for swarm_hip_count_active_noalloc.  Pass 1: workgroup g counts the ACTIVE
@@ -524,32 +538,45 @@ static void launch_aos_convert(const swarm_hip_ensemble_t *ens, const AosStage &
 
 static int grid_for(int nsys, int block) { return (int)(((long long)nsys + block - 1) / block); }
 
-// launch.hpp.  The list lives in stream-ordered memory (hipMallocAsync / hipFreeAsync on the launch stream): no
-// synchronisation, and launches on different streams of one GPU do not share it.  Layout: int32 count at [0], the
-// list from [64] on.
-int prepare_body_launch(const LaunchCtx &c, int G, EnsView &view, int &grid) {
-    view = c.ens;
+// launch.hpp.  The lists live in stream-ordered memory (hipMallocAsync / hipFreeAsync on the launch stream): no
+// synchronisation, and launches on different streams of one GPU do not share them.  Layout: int32 counts at [0] and
+// [1], the ACTIVE list from [64] on, the list of the others behind it.
+int prepare_body_launch(const LaunchCtx &c, int G, bool premonitor, BodyLaunch &bl) {
+    bl.view = bl.rest = c.ens;
+    bl.rest_grid = 0;
+    bl.mem = nullptr;
     const int n = c.effective_nsys();
-    grid = (int)(((long long)n + G - 1) / G);
+    bl.grid = (int)(((long long)n + G - 1) / G);
     if (n == c.ens.nsys) return SWARM_HIP_OK;
+    const size_t na = ((size_t)n + 63) / 64 * 64, nr = premonitor ? (size_t)c.ens.nsys : 0;
     int32_t *mem = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&mem, ((size_t)n + 64) * sizeof(int32_t), c.stream));
-    hipError_t err = hipMemsetAsync(mem, 0, sizeof(int32_t), c.stream);
+    HIP_TRY(hipMallocAsync((void **)&mem, (64 + na + nr) * sizeof(int32_t), c.stream));
+    hipError_t err = hipMemsetAsync(mem, 0, 2 * sizeof(int32_t), c.stream);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(active_list_kernel, dim3(grid_for(c.ens.nsys, 256)), dim3(256), 0, c.stream, c.ens, mem + 64, mem, n);
+        hipLaunchKernelGGL(active_list_kernel, dim3(grid_for(c.ens.nsys, 256)), dim3(256), 0, c.stream, c.ens, mem + 64, mem, n,
+                           premonitor ? mem + 64 + na : nullptr);
         err = hipGetLastError();
     }
     if (err != hipSuccess) {
         (void)hipFreeAsync(mem, c.stream);
         HIP_TRY(err);
     }
-    view.alist = mem + 64;
-    view.alist_n = mem;
-    view.alist_cap = n;
+    bl.mem = mem;
+    bl.view.alist = mem + 64;
+    bl.view.alist_n = mem;
+    bl.view.alist_cap = n;
+    if (premonitor) {
+        bl.rest.alist = mem + 64 + na;
+        bl.rest.alist_n = mem + 1;
+        bl.rest.alist_cap = c.ens.nsys;
+        // the hint may exceed the true count: room for every system (workgroups beyond the list return at once)
+        bl.rest_grid = (int)(((long long)c.ens.nsys + G - 1) / G);
+    }
     return SWARM_HIP_OK;
 }
-void finish_body_launch(const LaunchCtx &c, const EnsView &view) {
-    if (view.alist_n) (void)hipFreeAsync(const_cast<int32_t *>(view.alist_n), c.stream);
+void finish_body_launch(const LaunchCtx &c, BodyLaunch &bl) {
+    if (bl.mem) (void)hipFreeAsync(bl.mem, c.stream);
+    bl.mem = nullptr;
 }
 
 } // namespace swh

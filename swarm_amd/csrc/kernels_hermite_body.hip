@@ -201,12 +201,18 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
-    EnsView view;
-    int grid;
-    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
     const int monb = body_monitor_of(c.mp);
+    BodyLaunch bl;
+    if (int rc = prepare_body_launch(c, G, adaptive && monb != MONB_OFF, bl)) return rc;
+    // (the second launch: hermite_adap's monitor call before the loop for the systems that are not ACTIVE, launch.hpp)
 #define SWH_LAUNCH_BODY(M, AD)                                                                                         \
-    hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
+    do {                                                                                                               \
+        hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp,  \
+                           c.lg, c.cnt);                                                                               \
+        if (bl.rest_grid)                                                                                              \
+            hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(bl.rest_grid), dim3(W), 0, c.stream, bl.rest,     \
+                               c.ip, c.mp, c.lg, c.cnt);                                                               \
+    } while (0)
     if (adaptive) {
         if (monb == MONB_EJECTION)
             SWH_LAUNCH_BODY(MONB_EJECTION, true);
@@ -227,7 +233,7 @@ static int launch_body_n(const LaunchCtx &c, bool adaptive) {
             SWH_LAUNCH_BODY(MONB_OFF, false);
     }
 #undef SWH_LAUNCH_BODY
-    finish_body_launch(c, view);
+    finish_body_launch(c, bl);
     return check_launch("hermite (lane per body) kernel launch");
 }
 

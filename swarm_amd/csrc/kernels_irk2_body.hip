@@ -244,11 +244,10 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
     const double uround = cpu_rules ? 1e-16 : 2.221e-16;
     const int nitmax = cpu_rules ? 50 : 100;
     constexpr int G = W / N;
-    EnsView view;
-    int grid;
-    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
+    BodyLaunch bl;
+    if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
 #define SWH_LAUNCH_BODY(M)                                                                                              \
-    hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt, \
+    hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt, \
                        uround, nitmax, cpu_rules)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
@@ -257,7 +256,7 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
-    finish_body_launch(c, view);
+    finish_body_launch(c, bl);
     return check_launch("irk2 (lane per body) kernel launch");
 }
 

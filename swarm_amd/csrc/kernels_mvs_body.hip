@@ -253,11 +253,10 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 template <int N>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
-    EnsView view;
-    int grid;
-    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
+    BodyLaunch bl;
+    if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
 #define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
+    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
@@ -265,7 +264,7 @@ static int launch_body_n(const LaunchCtx &c) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
-    finish_body_launch(c, view);
+    finish_body_launch(c, bl);
     return check_launch("mvs (lane per body) kernel launch");
 }
 

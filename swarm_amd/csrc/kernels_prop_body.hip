@@ -280,11 +280,10 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
 template <int N, int KIND>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
-    EnsView view;
-    int grid;
-    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
+    BodyLaunch bl;
+    if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
 #define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
+    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
@@ -292,7 +291,7 @@ static int launch_body_n(const LaunchCtx &c) {
     default: SWH_LAUNCH_BODY(MONB_OFF); break;
     }
 #undef SWH_LAUNCH_BODY
-    finish_body_launch(c, view);
+    finish_body_launch(c, bl);
     return check_launch("propagator (lane per body) kernel launch");
 }
 

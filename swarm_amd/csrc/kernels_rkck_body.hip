@@ -163,12 +163,18 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
-    EnsView view;
-    int grid;
-    if (int rc = prepare_body_launch(c, G, view, grid)) return rc;
     const int monb = body_monitor_of(c.mp);
-#define SWH_LAUNCH_BODY(AD, M) \
-    hipLaunchKernelGGL((rkck_body_kernel<N, AD, M>), dim3(grid), dim3(W), 0, c.stream, view, c.ip, c.mp, c.lg, c.cnt)
+    BodyLaunch bl;
+    if (int rc = prepare_body_launch(c, G, monb != MONB_OFF, bl)) return rc;
+    // (the second launch: rkck's monitor call before the loop for the systems that are not ACTIVE, launch.hpp)
+#define SWH_LAUNCH_BODY(AD, M)                                                                                         \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((rkck_body_kernel<N, AD, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp,     \
+                           c.lg, c.cnt);                                                                               \
+        if (bl.rest_grid)                                                                                              \
+            hipLaunchKernelGGL((rkck_body_kernel<N, AD, M>), dim3(bl.rest_grid), dim3(W), 0, c.stream, bl.rest, c.ip,  \
+                               c.mp, c.lg, c.cnt);                                                                     \
+    } while (0)
 #define SWH_LAUNCH_BODY_MON(AD)                                       \
     switch (monb) {                                                   \
     case MONB_EJECTION: SWH_LAUNCH_BODY(AD, MONB_EJECTION); break;    \
@@ -183,7 +189,7 @@ static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     }
 #undef SWH_LAUNCH_BODY_MON
 #undef SWH_LAUNCH_BODY
-    finish_body_launch(c, view);
+    finish_body_launch(c, bl);
     return check_launch("rkck (lane per body) kernel launch");
 }
 

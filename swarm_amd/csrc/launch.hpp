@@ -24,10 +24,18 @@ struct LaunchCtx {
 // Lane-per-body launches (capi.hip).  prepare: `view` = the ensemble as the kernel sees it and `grid` = its workgroups
 // (one wavefront of G systems each).  When the caller's hint says that fewer systems are ACTIVE than the ensemble
 // holds, the ACTIVE ones are first gathered into a list on the device (stream-ordered allocation, one small kernel) and
-// the kernel walks that list: dense wavefronts for the tail of an adaptive or monitored run.  finish: gives the list
-// back (stream-ordered), after the kernel has been enqueued.
-int prepare_body_launch(const LaunchCtx &c, int G, EnsView &view, int &grid);
-void finish_body_launch(const LaunchCtx &c, const EnsView &view);
+// the kernel walks that list: dense wavefronts for the tail of an adaptive or monitored run.  `premonitor`: the
+// integrator calls its monitor once before the step loop for EVERY system (hermite_adap, rkck) -- the systems that are
+// not ACTIVE then get a launch of their own over `rest` (rest_grid workgroups; they take no steps), so that states
+// and log records stay what the ungathered launch produces.  finish: gives the lists back (stream-ordered), after
+// the kernels have been enqueued.
+struct BodyLaunch {
+    EnsView view, rest;
+    int grid, rest_grid;
+    int32_t *mem;
+};
+int prepare_body_launch(const LaunchCtx &c, int G, bool premonitor, BodyLaunch &bl);
+void finish_body_launch(const LaunchCtx &c, BodyLaunch &bl);
 
 void set_error(const char *fmt, ...);
 
