@@ -115,4 +115,6 @@ def test_attempt_loop_hands_the_count_on_and_logs_the_same(gpu, oracle):
     for k in ("pos", "vel", "time", "state"):
         assert np.array_equal(getattr(h1, k), getattr(h0, k)), k
     assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
-    assert r1 == r0 and len(r1) == (h1.state == O.DISABLED).sum() > 10
+    # (a disabled system still beyond rmax logs again at every launch: rkck calls its monitor before the loop for
+    # every system whatever its state, rkck_integrator.hpp:140 -- the gathered launches keep that)
+    assert r1 == r0 and len(set(r[0] for r in r1)) == (h1.state == O.DISABLED).sum() > 10 and len(r1) > 2 * 617
