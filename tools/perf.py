@@ -191,7 +191,15 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
         # rkck_integrator.hpp:75): lane-attempts and wave-attempts of each, for the utilisation over the whole run
         lane_att, wave_att, prev = float(att1.sum()), 64.0 * np.pad(att1.astype(np.float64), (0, (-len(att1)) % 64)).reshape(-1, 64).max(axis=1).sum(), att1
         launch_ms = [ms.value]
-        while integ._dens.count_active() != 0 and attempts < integ._max_attempts:
+        # per launch: ACTIVE systems when it started, attempts made in it (sum, and of its slowest system), and
+        # sum / (64 x sum over index-order wavefronts of the wave's slowest): the lane utilisation of that launch if it
+        # runs one lane per system without gathering
+        launches = [dict(active=int((host0.state == S.capi.ACTIVE).sum()), ms=round(ms.value, 4), attempts=int(att1.sum()),
+                         slowest=int(att1.max()), lane_utilisation=round(lane_utilisation(att1), 4))]
+        while True:
+            n_active = integ._dens.count_active()
+            if n_active == 0 or attempts >= integ._max_attempts:
+                break
             L.swarm_hip_event_record(e0, None)
             integ.launch_integrator()
             L.swarm_hip_event_record(e1, None)
@@ -206,6 +214,8 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
             prev = now
             lane_att += d.sum()
             wave_att += 64.0 * np.pad(d, (0, (-len(d)) % 64)).reshape(-1, 64).max(axis=1).sum()
+            launches.append(dict(active=int(n_active), ms=round(m2.value, 4), attempts=int(d.sum()), slowest=int(d.max()),
+                                 lane_utilisation=round(lane_utilisation(d), 4)))
         wall = time.perf_counter() - t0
         acc, att = integ.step_counts()
         integ.download_ensemble()
@@ -215,7 +225,7 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
                         log_bytes=lm.bytes_flushed if lm else 0, dropped=lm.dropped if lm else 0,
                         lane_utilisation=lane_utilisation(att1), lane_utilisation_all_launches=lane_att / max(wave_att, 1.0),
                         attempted_all_launches=int(att.sum()), kernel_ms_all_launches=sum(launch_ms),
-                        launch_ms=[round(x, 4) for x in launch_ms],
+                        launch_ms=[round(x, 4) for x in launch_ms], launches=launches,
                         accepted_min_max=[int(acc.min()), int(acc.max())],
                         states={int(k): int(v) for k, v in zip(*np.unique(host.state, return_counts=True))}))
     best = min(res, key=lambda r: r["ms"])
