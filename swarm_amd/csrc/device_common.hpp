@@ -582,6 +582,19 @@ __device__ __forceinline__ void mon_init(MonState &ms, const State<N> &s) {
     ms.next_log_time = s.t; // monitors/log_time_interval.hpp:118-119
 }
 
+// The first two early-outs of test_body (stop_on_ejection.hpp:112-117) without the square root: false means that the
+// body cannot meet the condition -- it is inside rmax for certain (r2 below a host-computed strict lower bound of
+// rmax^2) or not moving outwards (the reference's own `rdotv <= 0` test, same operations).  The kernels evaluate it for
+// every planet on every step and reach the monitor proper only when some lane of the wavefront answers true: with the
+// second test a planet that sits beyond rmax on a bound orbit (rmax inside the outermost orbit) stops costing a
+// monitor call per step.
+__device__ __forceinline__ bool ej_maybe_body(const double (&p)[3], const double (&v)[3], const MonParams &mp) {
+#pragma clang fp contract(off)
+    const double r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    const double rdotv = p[0] * v[0] + p[1] * v[1] + p[2] * v[2];
+    return !(r2 < mp.r2_below) && !(rdotv <= 0.);
+}
+
 // stop_on_ejection::test_body, monitors/stop_on_ejection.hpp:108-138
 // VERBOSE (compile time) = the kernel variant that can emit lprintf records: the out-of-line
 // formatter call costs registers in the step loop, so launches without verbose_on_* flags use
@@ -681,8 +694,7 @@ __device__ __forceinline__ bool mon_pass_one(MonState &ms, const State<N> &s, co
 #pragma clang fp contract(off)
 #pragma unroll
             for (int b = 1; b < N; b++) {
-                const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                maybe = maybe || !(r2 < mp.r2_below);
+                maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
             }
         }
         if (__any(maybe)) {
@@ -737,8 +749,7 @@ __device__ __forceinline__ void mon_call(MonState &ms, State<N> &s, const MonPar
 #pragma clang fp contract(off)
 #pragma unroll
             for (int b = 1; b < N; b++) {
-                const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                maybe = maybe || !(r2 < mp.r2_below);
+                maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
             }
         }
         if (!__any(maybe)) {

@@ -363,8 +363,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
-                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                        maybe = maybe || !(r2 < mp.r2_below);
+                        maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
                     }
                 }
                 if (__any(maybe)) {

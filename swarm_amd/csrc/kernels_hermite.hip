@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
-                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                        maybe = maybe || !(r2 < mp.r2_below);
+                        maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
                     }
                 }
                 if (__any(maybe)) {
@@ -95,8 +94,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
-                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                        maybe = maybe || !(r2 < mp.r2_below);
+                        maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
                     }
                 }
                 if (__any(maybe)) {

@@ -156,8 +156,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 #pragma clang fp contract(off)
 #pragma unroll
                     for (int b = 1; b < N; b++) {
-                        const double r2 = s.p[b][0] * s.p[b][0] + s.p[b][1] * s.p[b][1] + s.p[b][2] * s.p[b][2];
-                        maybe = maybe || !(r2 < mp.r2_below);
+                        maybe = maybe || ej_maybe_body(s.p[b], s.v[b], mp);
                     }
                 }
             }
