@@ -64,13 +64,16 @@ def secondary_block():
                               ("c3_rkck_adaptive_divergent", "c3_div", {"shuffle": True}),
                               ("c4_mvs_shard", "c4", {}),
                               ("c5_hermite_adap_log", "c5", {})):
-        r = perf.measure(workload, reps=2, host_to_host=False, warm=True, **kw)
-        keep = {k: r[k] for k in ("integrator", "nsys", "nbod", "T", "ms", "accepted", "attempted", "attempts",
-                                  "accepted_steps_per_s", "attempted_steps_per_s", "flop_per_step", "algorithmic_tflops",
-                                  "frac_of_fp64_peak", "lane_utilisation_all_launches", "kernel_ms_all_launches",
+        r = perf.measure(workload, reps=5, host_to_host=False, warm=True, **kw)
+        keep = {k: r[k] for k in ("integrator", "nsys", "nbod", "T", "ms", "ms_min_max", "reps", "accepted", "attempted",
+                                  "attempts", "accepted_steps_per_s", "attempted_steps_per_s", "flop_per_step",
+                                  "algorithmic_tflops", "frac_of_fp64_peak", "lane_utilisation_all_launches",
+                                  "kernel_ms_all_launches", "kernel_ms_all_launches_min_max", "launches",
                                   "log_bytes", "flush_ms") if k in r}
-        keep["ms_is"] = ("first launch of the run, HIP events on the launch stream; the same launch on a copy of the "
-                         "ensemble is enqueued directly ahead of it so that it does not start at an idle clock")
+        keep["ms_is"] = ("first launch of the run, HIP events on the launch stream, of the MEDIAN repetition of 5 (by kernel "
+                         "time over all launches of the run; min and max beside it); the same launch on a copy of the "
+                         "ensemble is enqueued directly ahead of the timed one so that it does not start at an idle clock")
+        keep["reproduce"] = "python tools/perf.py %s %s--warm --no-host-to-host --reps 5" % (workload, "--shuffle " if kw.get("shuffle") else "")
         out[tag] = keep
     return out
 
@@ -86,7 +89,7 @@ def lane_per_body_block():
                               ("rkck_adaptive_2048x6_100_attempts", "c3", dict(nsys=2048))):
         ms = {}
         for name, mode in (("lane_per_system_ms", 1), ("library_choice_ms", 0)):
-            ms[name] = perf.measure(workload, reps=2, host_to_host=False, warm=True, lane_mode=mode, **kw)["ms"]
+            ms[name] = perf.measure(workload, reps=3, host_to_host=False, warm=True, lane_mode=mode, **kw)["ms"]
         out[tag] = ms
     return out
 
