@@ -190,7 +190,9 @@ int swarm_hip_count_active(const swarm_hip_ensemble_t *ens, void *stream, int32_
  * be cleared).  Calls no hipMalloc/hipFree: the per-workgroup partial counts live in a static device array
  * of 64 KiB that every GPU the library runs on holds until the process ends (one int32 per 4096 systems),
  * hence the limit nsys <= SWARM_HIP_NOALLOC_MAX_NSYS (larger: SWARM_HIP_EINVAL).  All calls on one GPU
- * share that array: calls that overlap on one GPU (two streams, two host threads) race -- order them. */
+ * share that array: calls that overlap on one GPU (two streams, two host threads) race -- order them.
+ * swarm_hip_init(device) must have run for the current device (it resolves the array's address there, once);
+ * without it the call returns SWARM_HIP_EINVAL.  The call itself takes no lock. */
 #define SWARM_HIP_NOALLOC_MAX_NSYS (1 << 26)
 int swarm_hip_count_active_noalloc(const swarm_hip_ensemble_t *ens, int32_t *d_count, void *stream);
 

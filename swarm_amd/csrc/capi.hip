@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "launch.hpp"
@@ -101,10 +102,12 @@ static int scratch_for_current(int32_t **out, std::unique_lock<std::mutex> &hold
 constexpr int NOALLOC_SYS_PER_GROUP = 4096;                    // 256 threads x 16 systems
 constexpr int NOALLOC_GROUPS = SWARM_HIP_NOALLOC_MAX_NSYS / NOALLOC_SYS_PER_GROUP; // 16384
 static __device__ __align__(256) int32_t scratch[NOALLOC_GROUPS];
-static int32_t *g_noalloc_ptr[MAX_DEV] = {nullptr};
+// Resolved once per device by swarm_hip_init (with that device current) and only read afterwards: the entry point
+// itself takes no lock and makes no call that could load code or allocate.
+static std::atomic<int32_t *> g_noalloc_ptr[MAX_DEV];
 static std::mutex g_noalloc_mu;
 
-static int noalloc_scratch(int32_t **out) {
+static int noalloc_resolve_current() { // swarm_hip_init
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEV) {
@@ -112,12 +115,24 @@ static int noalloc_scratch(int32_t **out) {
         return SWARM_HIP_EINVAL;
     }
     std::lock_guard<std::mutex> lock(g_noalloc_mu);
-    if (!g_noalloc_ptr[dev]) {
+    if (!g_noalloc_ptr[dev].load()) {
         int32_t *p = nullptr;
         HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
-        g_noalloc_ptr[dev] = p;
+        g_noalloc_ptr[dev].store(p);
     }
-    *out = g_noalloc_ptr[dev];
+    return SWARM_HIP_OK;
+}
+
+static int noalloc_scratch(int32_t **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int32_t *p = (dev >= 0 && dev < MAX_DEV) ? g_noalloc_ptr[dev].load(std::memory_order_acquire) : nullptr;
+    if (!p) {
+        set_error("count_active_noalloc: device %d has not been set up -- call swarm_hip_init(%d) first (it resolves the "
+                  "device's copy of the static scratch array; this entry point does no set-up of its own)", dev, dev);
+        return SWARM_HIP_EINVAL;
+    }
+    *out = p;
     return SWARM_HIP_OK;
 }
 
@@ -595,7 +610,7 @@ int swarm_hip_init(int device) {
     std::unique_lock<std::mutex> hold;
     int rc = scratch_for_current(&s, hold);
     if (rc) return rc;
-    return noalloc_scratch(&s); // resolve this device's copy of the static scratch array now
+    return noalloc_resolve_current(); // this device's copy of the static scratch array
 }
 
 int64_t swarm_hip_nchunk(int32_t nsys) { return ((int64_t)nsys + W - 1) / W; }

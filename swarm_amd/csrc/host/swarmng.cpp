@@ -743,7 +743,10 @@ struct rec_t {
     }
     bool operator<(const rec_t &a) const { // by time, then system, then position in the file
         const double Tt = T(), Ta = a.T();
-        if (Tt != Ta) return Tt < Ta;
+        // (a NaN time, possible only in a damaged file, orders before every number: a strict weak ordering for std::sort)
+        const bool nt = Tt != Tt, na = Ta != Ta;
+        if (nt != na) return nt;
+        if (!nt && Tt != Ta) return Tt < Ta;
         const int st = sys(), sa = a.sys();
         return st != sa ? st < sa : ptr < a.ptr;
     }
@@ -768,7 +771,8 @@ static std::vector<rec_t> index_records(const std::vector<char> &data) {
         rec_t r;
         r.ptr = data.data() + off;
         memcpy(&r.len, r.ptr + 4, 4);
-        if (r.len <= 0 || off + (size_t)r.len > data.size()) ERROR("corrupt log record");
+        // a record is at least its own 8-byte header, a multiple of 8 long (gpulog pads to 16) and inside the file
+        if (r.len < 8 || r.len % 8 != 0 || off + (size_t)r.len > data.size()) ERROR("corrupt log record");
         idx.push_back(r);
         off += (size_t)r.len;
     }
@@ -808,9 +812,10 @@ static lbody center_of_mass(const lbody *bodies, const int nbod) { // query.cpp:
 static void record_output_1(std::ostream &out, const rec_t &r, const body_range_t &body_range) {
     double time = r.T();
     int sys = r.sys(), flags, nbod;
+    if (r.len < 32) ERROR("corrupt log record"); // before anything is read from it
     memcpy(&flags, r.ptr + 20, 4);
     memcpy(&nbod, r.ptr + 24, 4);
-    if (r.len < 32 || nbod < 0 || 32 + (long long)sizeof(lbody) * nbod > r.len) ERROR("corrupt log record");
+    if (nbod < 1 || 32 + (long long)sizeof(lbody) * nbod > r.len) ERROR("corrupt log record");
     std::vector<lbody> bodies(nbod);
     memcpy((void *)bodies.data(), r.ptr + 32, sizeof(lbody) * nbod);
     lbody center;

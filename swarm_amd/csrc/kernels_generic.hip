@@ -246,7 +246,17 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
             hk.set(ip.time_step);
         }
 
+        bool stored = false;
         for (int iter = 0; iter < ip.max_iterations && (WHOLE ? __any(live) : live); iter++) {
+            // A system that is done hands its state back at once (prop.shutdown() + store): from here on its lane only
+            // keeps the wave whole, and whatever those h = 0 steps leave in its registers -- unchanged values as long
+            // as its forces are finite, NaN otherwise (0 * inf) -- is never written back.
+            if (WHOLE && mine && !live && !stored) {
+                if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
+                store_state(e, gid, s);
+                if (KIND == SWARM_HIP_MVS) mvs_to_internal(s);
+                stored = true;
+            }
             double max_timestep;
             {
 #pragma clang fp contract(off)
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
         }
         // prop.shutdown()
         if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
-        if (mine) store_state(e, gid, s);
+        if (mine && !stored) store_state(e, gid, s);
     }
     if (ghost) return;
     if (cnt.accepted) cnt.accepted[gid] += steps;

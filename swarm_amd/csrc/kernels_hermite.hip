@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         mon_call<N, MON == MON_VERBOSE>(ms, s, mp, lg, true);
 
     unsigned long long steps = 0;
+    bool stored = false; // the state has been written back already (general loop)
     // WHOLE: the wave is kept whole through ragged ends (general loop below).  Not for the fixed-step kernel with
     // nothing to monitor -- Hermite.cfg as shipped, the headline: its lanes all take the same steps unless their start
     // times differ, and the extra control flow cost that kernel 3 % (16.88 -> 17.38 ms, A/B on one box).
@@ -148,6 +149,13 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         auto live = [&]() { return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; };
         while (WHOLE ? __any(live()) : live()) {
             const bool on = !WHOLE || live();
+            // A system that is done hands its state back at once: from here on its lane only keeps the wave whole, and
+            // whatever those h = 0 steps leave in its registers -- unchanged values as long as its forces are finite,
+            // NaN otherwise (0 * inf) -- is never written back.
+            if (WHOLE && !on && !stored) {
+                if (steps || s.state != state_in) store_state(e, gid, s);
+                stored = true;
+            }
             double h;
             if (ADAPTIVE) {
                 // calc_adaptive_time_step, hermite_adap.hpp:69-98: sum over bodies of |jerk|^2/|acc|^2
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         }
     }
     if (ghost) return;
-    if (steps || s.state != state_in) store_state(e, gid, s);
+    if (!stored && (steps || s.state != state_in)) store_state(e, gid, s);
     if (cnt.accepted) cnt.accepted[gid] += steps;
     if (cnt.attempted) cnt.attempted[gid] += steps;
 }

@@ -67,9 +67,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
 #pragma clang fp contract(off)
             if (s.t + h > dest) h = dest - s.t;
         }
-        // fixed step: every attempt is committed, so a lane that only keeps the wave whole takes h = 0, which leaves
-        // its registers exactly as they are (p + 0 * (...) = p); the adaptive form withholds the commit instead
-        if (!ADAPTIVE && !live) h = 0.0;
+        // (a lane that only keeps the wave whole computes its attempt like the others and never commits it)
         double ka[6][N][3];
         double sp[N][3];
 #pragma unroll
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256) void rkck_kernel(EnsView e, IntParams ip, MonP
         }
         bool accept_step = true;
         if (ADAPTIVE) accept_step = rkck_step_control(max_error, time_step, ip); // L204-269
-        if (ADAPTIVE) accept_step = accept_step && live;
+        accept_step = accept_step && live;
         if (live) attempted++;
         if (accept_step) {
 #pragma unroll
