@@ -252,9 +252,6 @@ __device__ __forceinline__ void acc_only(const double (&p)[N][3], const double (
 // returns whether this lane is a ghost.  A full wave of active systems pays one ballot.
 template <int N>
 __device__ __forceinline__ bool take_ghosts(const bool mine, State<N> &s) {
-#ifdef SWH_NO_GHOSTS // A/B builds (tools/variant.sh)
-    return false;
-#endif
     const unsigned long long active = __ballot(mine);
     const int nlive = __popcll(active);
     if (nlive == 0 || nlive > 8) return false; // wave-uniform
@@ -345,9 +342,7 @@ struct StepConsts {
 // `vp` = the velocity the POSITION predictor uses: the reference kernel predicts from the global
 // pos/vel but with its register copy of vel (hermite_integrator.hpp:124-132); the two differ only
 // after a monitor rewrote the system (mce_stat merges).
-#ifndef SWH_HERMITE_FOLD_FROM
-#define SWH_HERMITE_FOLD_FROM 9
-#endif
+constexpr int HERMITE_FOLD_FROM = 9;
 template <int N>
 __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, const double (&a0)[N][3],
                                              const double (&j0)[N][3], double (&a1)[N][3],
@@ -357,7 +352,7 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
     // at the price of one more rounding per step in v.  Fixed-step kernel, 65536 systems: nbod 9 132 B of scratch -> 0
     // (0.56 -> 0.66 of FP64 peak), nbod 10 384 -> 220 B (0.38 -> 0.48).  (Keeping pp and c0 in LDS instead was tried:
     // the scheduler hoists the reads above the force evaluation and spills more than before, volatile or not.)
-    constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM;
+    constexpr bool FOLD = N >= HERMITE_FOLD_FROM;
     double pp[N][3], pv[N][3], c0[N][3], d0[FOLD ? 1 : N][3];
 #pragma unroll
     for (int b = 0; b < N; b++)

@@ -31,14 +31,12 @@ __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], d
 #pragma unroll
         for (int g = 0; g < G; g++) SC_series(y[g], S[g], C[g]);
     } else {
-#ifndef SWH_EXPERIMENT_SERIES_ONLY /* ceiling experiment: no general Stumpff path at all; never in the shipped build */
 #pragma unroll
         for (int g = 0; g < G; g++) {
             double sc[2];
             SC_prussing_outlined(y[g], sc);
             S[g] = sc[0], C[g] = sc[1];
         }
-#endif
     }
 }
 
@@ -81,10 +79,7 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerCons
 }
 
 // all planets 1..N-1, in groups of at most KEPLER_GROUP (register budget: 6 doubles per planet)
-#ifndef SWH_KEPLER_GROUP
-#define SWH_KEPLER_GROUP 2 // measured on MI355X, C4 shard (ms per 1001 steps): G=1 20.7, 2 18.5, 4 19.7, 7 20.9
-#endif
-constexpr int KEPLER_GROUP = SWH_KEPLER_GROUP;
+constexpr int KEPLER_GROUP = 2; // measured on MI355X, C4 shard (ms per 1001 steps): G=1 20.7, 2 18.5, 4 19.7, 7 20.9
 template <int N, int B0 = 1>
 __device__ __forceinline__ void drift_kepler_all(State<N> &s, const KeplerConsts &k, const bool compensated) {
     if constexpr (B0 < N) {

@@ -26,7 +26,7 @@ template <int N, int MONB, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     constexpr int G = W / N; // systems per wavefront
-    constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM;
+    constexpr bool FOLD = N >= HERMITE_FOLD_FROM;
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;

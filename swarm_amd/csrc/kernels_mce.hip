@@ -22,7 +22,13 @@ __global__ __launch_bounds__(256) void hermite_mce_kernel(EnsView e, IntParams i
 
     unsigned long long steps = 0;
     bool rewritten = false;
-    if (s.state == SWARM_HIP_ACTIVE) {
+    // The wave goes through its steps whole: a lane whose system is done -- end of the integration, a
+    // halt after a collision, the iteration budget -- or was not ACTIVE at launch hands its state back at once and
+    // then only keeps the wave company with steps of h = 0, unmonitored, never stored: MI355X issues FP64 instructions
+    // at a third of the rate once 8 or fewer lanes of a wavefront are enabled, and a run of mce_stat ends with a few
+    // surviving systems per wave.
+    bool stored = false;
+    if (__any(s.state == SWARM_HIP_ACTIVE)) {
         double fa[2][N][3], fj[2][N][3], vreg[N][3], cp[N][3], cv[N][3];
         accjerk<N>(s.p, s.v, s.m, fa[0], fj[0]);
 #pragma unroll
@@ -32,12 +38,21 @@ __global__ __launch_bounds__(256) void hermite_mce_kernel(EnsView e, IntParams i
         const double dest = ip.destination_time;
         StepConsts k;
         k.set(ip.time_step);
-        for (int iter = 0; iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; iter++) {
+        int iter = 0;
+        auto live = [&]() { return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; };
+        while (__any(live())) {
+            const bool on = live();
+            if (!on && !stored) {
+                if (steps) store_state(e, gid, s);
+                if (rewritten) mce_store_masses<N>(e, gid, s);
+                stored = true;
+            }
             double h = ip.time_step;
             {
 #pragma clang fp contract(off)
                 if (s.t + h > dest) h = dest - s.t;
             }
+            if (!on) h = 0.0;
             if (h != k.h) k.set(h);
 #pragma unroll
             for (int b = 0; b < N; b++)
@@ -53,17 +68,22 @@ __global__ __launch_bounds__(256) void hermite_mce_kernel(EnsView e, IntParams i
                     vreg[b][c] = s.v[b][c];
                     fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
                 }
-            s.t += h;
-            steps++;
-            if (mce_monitor<N>(e, gid, s, cp, cv, md, mp.mce_time_step, lg)) rewritten = true;
-            if (s.state == SWARM_HIP_ACTIVE) {
+            if (on) {
+                s.t += h;
+                steps++;
+                iter++;
+                if (mce_monitor<N>(e, gid, s, cp, cv, md, mp.mce_time_step, lg)) rewritten = true;
+                if (s.state == SWARM_HIP_ACTIVE) {
 #pragma clang fp contract(off)
-                if (s.t > dest - 1e-12) s.state = SWARM_HIP_INACTIVE; // hermite_integrator.hpp:177-179
+                    if (s.t > dest - 1e-12) s.state = SWARM_HIP_INACTIVE; // hermite_integrator.hpp:177-179
+                }
             }
         }
     }
-    if (steps) store_state(e, gid, s);
-    if (rewritten) mce_store_masses<N>(e, gid, s);
+    if (!stored) {
+        if (steps) store_state(e, gid, s);
+        if (rewritten) mce_store_masses<N>(e, gid, s);
+    }
     if (cnt.accepted) cnt.accepted[gid] += steps;
     if (cnt.attempted) cnt.attempted[gid] += steps;
 }

@@ -22,7 +22,7 @@ template <int N, int KIND, int MONB>
 __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF;
-    constexpr bool FOLD = N >= SWH_HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
+    constexpr bool FOLD = N >= HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;

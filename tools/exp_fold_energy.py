@@ -1,5 +1,5 @@
 """Energy conservation of the fixed-step Hermite kernel at nbod 9 with and without the velocity fold of hermite_step
-(device_common.hpp, nbod >= 9): run under SWARM_HIP_LIB=<variant built with -DSWH_HERMITE_FOLD_FROM=99> and without.
+(device_common.hpp, nbod >= 9): run under SWARM_HIP_LIB=<variant built with HERMITE_FOLD_FROM = 99 in device_common.hpp> and without.
 Prints max and median |dE/E| over the ensemble after 1e5 steps of 1e-3."""
 import sys
 import numpy as np

@@ -2,7 +2,9 @@
 # Kernel-variant experiments: rebuild ONE translation unit of libswarm_hip.so with extra flags and link it with
 # the shipped objects into swarm_amd/lib/variants/libswarm_hip_<tag>.so (select it with SWARM_HIP_LIB=...).
 #   tools/variant.sh <tag> <source.hip> [extra hipcc flags...]
-# e.g. tools/variant.sh kg4 kernels_generic.hip -DSWH_DISPATCH_ONLY=8 -DSWH_KEPLER_GROUP=4
+# e.g. tools/variant.sh n8 kernels_generic.hip -DSWH_DISPATCH_ONLY=8      (instantiate nbod 8 only: a quick build)
+# The shipped sources carry no experiment switches other than SWH_DISPATCH_ONLY (launch.hpp); a variant is an edit of
+# the source under test, built here beside the shipped library.
 set -e
 tag=$1; src=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
