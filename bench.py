@@ -50,8 +50,14 @@ def profiled_traffic(tag):
             c = json.load(open(fn))
             c = c.get("counters", c)
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return {"bytes": c["FETCH_SIZE"]["per_launch_avg"] * 1024 * 2 + c["WRITE_SIZE"]["per_launch_avg"] * 1024,
-                        "source": os.path.relpath(fn, ROOT)}
+                out = {"bytes": c["FETCH_SIZE"]["per_launch_avg"] * 1024 * 2 + c["WRITE_SIZE"]["per_launch_avg"] * 1024,
+                       "source": os.path.relpath(fn, ROOT), "issued_flop": None}
+                ops = [c.get("SQ_INSTS_VALU_%s_F64" % k, {}).get("per_launch_avg") for k in ("ADD", "MUL", "FMA", "TRANS")]
+                if None not in ops:
+                    # FP64 flop ISSUED per launch: wave-instructions x 64 lanes, FMA counted twice (the launches of this
+                    # command run with every lane enabled)
+                    out["issued_flop"] = 64.0 * (ops[0] + ops[1] + 2.0 * ops[2] + ops[3])
+                return out
     return None
 
 
@@ -306,6 +312,11 @@ def main():
                      # the MI355X guide + WRITE_SIZE), profiles/r1/hermite_n3_pmc.json; algorithmic = 340 B/system
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
+                     # FP64 flop the kernel ISSUES (SQ_INSTS_VALU_{ADD,MUL,FMA x 2,TRANS}_F64 x 64 lanes per launch, from
+                     # the same committed PMC passes) over this run's kernel time, as a fraction of the same peak:
+                     # `frac` counts the reference's formulas, this counts the instructions
+                     "issued_frac": (traffic["issued_flop"] / (kernel_ms_avg * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+                                     if traffic and traffic.get("issued_flop") and kernel_ms_avg > 0 else None),
                      "kernel": "hermite_kernel<%d,false,0>" % nbod,
                      "kernel_ms_avg": kernel_ms_avg,
                      "flop_per_system_step": flops,
