@@ -17,6 +17,13 @@
 
 namespace swh {
 
+// `kepler_compensated=1` is a second MVS kernel, not a branch in the first: kepler_end's two forms of the f, g update
+// differ in ~10 operations per planet, and told apart at run time (a wave-uniform branch per planet and coordinate)
+// they cost the step 77 scalar branches and the moves that merge the two paths.  Internal id, not in the C-ABI.
+constexpr int KIND_MVS_COMPENSATED = 100 + SWARM_HIP_MVS;
+template <int KIND>
+constexpr bool is_mvs = KIND == SWARM_HIP_MVS || KIND == KIND_MVS_COMPENSATED;
+
 // Kepler drift of G planets in lockstep (the per-planet pieces are in mvs_common.hpp), with the Laguerre iterations of
 // the G planets advancing together so that their G independent dependency chains interleave (one lane owns the whole
 // system, so without this every iteration is one long serial chain of FP64 latencies).  The Stumpff functions take the
@@ -40,8 +47,8 @@ __device__ __forceinline__ void SC_group(const double (&y)[G], double (&S)[G], d
     }
 }
 
-template <int N, int B0, int G>
-__device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerConsts &k, const bool compensated) {
+template <int N, int B0, int G, bool COMPENSATED>
+__device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerConsts &k) {
     KeplerOrbit o[G];
 #pragma unroll
     for (int g = 0; g < G; g++) kepler_begin(o[g], s.p[B0 + g], s.v[B0 + g], k);
@@ -75,20 +82,29 @@ __device__ __forceinline__ void drift_kepler_group(State<N> &s, const KeplerCons
     for (int g = 0; g < G; g++) y[g] = kepler_y(o[g]);
     SC_group<G>(y, Sp, Cp);
 #pragma unroll
-    for (int g = 0; g < G; g++) kepler_end(o[g], k, y[g], Sp[g], Cp[g], compensated, true, s.p[B0 + g], s.v[B0 + g]);
+    for (int g = 0; g < G; g++) kepler_end(o[g], k, y[g], Sp[g], Cp[g], COMPENSATED, true, s.p[B0 + g], s.v[B0 + g]);
 }
 
-// all planets 1..N-1, in groups of at most KEPLER_GROUP (register budget: 6 doubles per planet)
-constexpr int KEPLER_GROUP = 2; // measured on MI355X, C4 shard (ms per 1001 steps): G=1 20.7, 2 18.5, 4 19.7, 7 20.9
-template <int N, int B0 = 1>
-__device__ __forceinline__ void drift_kepler_all(State<N> &s, const KeplerConsts &k, const bool compensated) {
+// all planets 1..N-1 in lockstep groups.  Pairs, an odd planet out joining the first group (3, 2, 2 ... instead of going
+// alone at the end, where its passes would be one serial chain); four planets of nbod 5 and the first four of nbod 8's
+// seven go together (4 and 4, 3).  Measured on MI355X, 131072 systems, ms per 1001 steps (round 3,
+// profiles/r3/mvs_grouping_sweep.txt), pairs / balanced groups of at most 3 / of at most 4:
+//   nbod 5  4.87 / 4.94 / 4.77     nbod 8  9.05 / 9.06 / 8.86     nbod 9  10.9 / 11.5 / 12.3     nbod 10  13.4 / 14.9 / 14.9
+// (larger groups spill: 6 doubles per planet of a group are live across its passes); nbod 3, 4, 6, 7 within the noise.
+constexpr int KEPLER_GROUP = 2;
+constexpr int kepler_group_size(const int n, const int b0, const bool wide) {
+    const int rem = n - b0;
+    if (wide && b0 == 1 && (n == 5 || n == 8)) return 4;
+    return (rem % KEPLER_GROUP == 1 && rem > 1) ? KEPLER_GROUP + 1 : (rem < KEPLER_GROUP ? rem : KEPLER_GROUP);
+}
+// WIDE: the groups of four; not with a monitor bound, whose kernel has no registers to spare (nbod 8 with the ejection
+// monitor armed: 1440 instead of 800 bytes of scratch per lane, 18.6 instead of 15.9 ms on the C4 shard)
+template <int N, bool COMPENSATED, bool WIDE, int B0 = 1>
+__device__ __forceinline__ void drift_kepler_all(State<N> &s, const KeplerConsts &k) {
     if constexpr (B0 < N) {
-        // an odd planet out joins the first group (3, 2, 2 for seven planets) instead of going alone at the end, where
-        // its passes would be one serial chain: C4 shard 9.76 -> 9.66 ms, nbod 4 4.04 -> 3.87, 6 6.60 -> 6.46, 10 14.5 -> 14.3
-        constexpr int REM = N - B0;
-        constexpr int G = (REM % KEPLER_GROUP == 1 && REM > 1) ? KEPLER_GROUP + 1 : (REM < KEPLER_GROUP ? REM : KEPLER_GROUP);
-        drift_kepler_group<N, B0, G>(s, k, compensated);
-        drift_kepler_all<N, B0 + G>(s, k, compensated);
+        constexpr int G = kepler_group_size(N, B0, WIDE);
+        drift_kepler_group<N, B0, G, COMPENSATED>(s, k);
+        drift_kepler_all<N, COMPENSATED, WIDE, B0 + G>(s, k);
     }
 }
 
@@ -143,16 +159,26 @@ __device__ __forceinline__ void mvs_to_std(State<N> &s) {
 // MVSPropagator::drift_step, mvs.hpp:242-256
 // (`/ m0` is a multiplication by the launch-constant 1/m0: 1 ulp from the reference's quotient, 6 IEEE
 // divides per step less)
+// The planets' momentum sum of a drift is a function of the velocities alone, and nothing touches them between the
+// drift that ends one step and the drift that begins the next: with no monitor bound the second sum of a step is kept
+// for the first of the next (the same operations on the same operands, 3 (N-1) FMAs per step fewer).
 template <int N>
-__device__ __forceinline__ void mvs_drift(State<N> &s, double hby2, double inv_m0) {
+__device__ __forceinline__ void mvs_momentum(const State<N> &s, double (&mv)[3]) {
 #pragma clang fp contract(off)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        double mv = 0;
+        mv[c] = 0;
 #pragma unroll
-        for (int j = 1; j < N; ++j) mv = __builtin_fma(s.m[j], s.v[j][c], mv);
+        for (int j = 1; j < N; ++j) mv[c] = __builtin_fma(s.m[j], s.v[j][c], mv[c]);
+    }
+}
+template <int N>
+__device__ __forceinline__ void mvs_drift(State<N> &s, const double (&mv)[3], double hby2, double inv_m0) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
         s.p[0][c] = __builtin_fma(hby2, s.v[0][c], s.p[0][c]);
-        const double shift = (mv * hby2) * inv_m0; // one product for all planets, then plain additions
+        const double shift = (mv[c] * hby2) * inv_m0; // one product for all planets, then plain additions
 #pragma unroll
         for (int b = 1; b < N; b++) s.p[b][c] = s.p[b][c] + shift;
     }
@@ -185,19 +211,19 @@ __device__ __attribute__((noinline)) void generic_mon_call(MonState *ms, State<N
     State<N> &s = *sp;
     const MonParams &mp = *mpp;
     const bool needs_std = mon_pass_one<N, false>(*ms, s, mp, *lgp);
-    if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
+    if (is_mvs<KIND> && needs_std) mvs_to_std(s);
     mon_pass_two(*ms, s, mp);
     const bool want = mon_need_log(*ms, mp);
     if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
         if (__any(want)) log_system(*lgp, s, want);
-    if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_internal(s);
+    if (is_mvs<KIND> && needs_std) mvs_to_internal(s);
 }
 
 // MVS keeps two waves per SIMD (<= 256 registers, a few spilled doubles from nbod 5 on): its Kepler solver is a
 // chain of dependent FP64 operations with quarter-rate reciprocals, and a second resident wave hides them
 // (131072 x 5..8: -15..20 %; at one wave of work per SIMD, 65536 systems, +2..3 %).
 template <int N, int KIND, int MON>
-__global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
+__global__ __launch_bounds__(256, is_mvs<KIND> ? 2 : 1) void generic_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg,
                                                       Counters cnt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= e.nsys) return;
@@ -225,11 +251,13 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
         double timestep = 0.;
         const double inv_m0 = 1.0 / s.m[0];
         KeplerConsts kc;
+        double mv[3] = {0., 0., 0.}; // MVS: the planets' momentum sum (mvs_momentum)
         // prop.init()
-        if (KIND == SWARM_HIP_MVS) {
+        if (is_mvs<KIND>) {
             kc.set_star(sqrt(s.m[0]));
             mvs_to_internal(s);
             acc_only<N, true>(s.p, s.m, acc);
+            mvs_momentum(s, mv);
         } else if (KIND == SWARM_HIP_VERLET) {
             timestep = verlet_timestep(s, ip);
         }
@@ -247,9 +275,9 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
             // keeps the wave whole, and whatever those h = 0 steps leave in its registers -- unchanged values as long
             // as its forces are finite, NaN otherwise (0 * inf) -- is never written back.
             if (WHOLE && mine && !live && !stored) {
-                if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
+                if (is_mvs<KIND>) mvs_to_std(s);
                 store_state(e, gid, s);
-                if (KIND == SWARM_HIP_MVS) mvs_to_internal(s);
+                if (is_mvs<KIND>) mvs_to_internal(s);
                 stored = true;
             }
             double max_timestep;
@@ -257,21 +285,23 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
 #pragma clang fp contract(off)
                 max_timestep = dest - s.t;
             }
-            if (KIND == SWARM_HIP_MVS) { // MVSPropagator::advance, mvs.hpp:260-293
+            if (is_mvs<KIND>) { // MVSPropagator::advance, mvs.hpp:260-293
                 const double hby2 = (!WHOLE || live) ? 0.5 * fmin(max_timestep, ip.time_step) : 0.0;
-                mvs_drift(s, hby2, inv_m0);
+                if (MON != MON_OFF) mvs_momentum(s, mv); // a monitor may have taken the state through standard coordinates
+                mvs_drift(s, mv, hby2, inv_m0);
 #pragma unroll
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] = __builtin_fma(hby2, acc[b][c], s.v[b][c]);
                 if (2.0 * hby2 != kc.dt) kc.set_dt(2.0 * hby2);
-                drift_kepler_all<N>(s, kc, ip.kepler_compensated != 0);
+                drift_kepler_all<N, KIND == KIND_MVS_COMPENSATED, MON == MON_OFF>(s, kc);
                 acc_only<N, true>(s.p, s.m, acc);
 #pragma unroll
                 for (int b = 1; b < N; b++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) s.v[b][c] = __builtin_fma(hby2, acc[b][c], s.v[b][c]);
-                mvs_drift(s, hby2, inv_m0);
+                mvs_momentum(s, mv);
+                mvs_drift(s, mv, hby2, inv_m0);
                 s.t += 2.0 * hby2;
             } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
                 const double h = (!WHOLE || live) ? fmin(ip.time_step, max_timestep) : 0.0;
@@ -380,18 +410,18 @@ __global__ __launch_bounds__(256, KIND == SWARM_HIP_MVS ? 2 : 1) void generic_ke
                 }
             } else if (MON) {
                 const bool needs_std = mon_pass_one<N, MON == MON_VERBOSE>(ms, s, mp, lg);
-                if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_std(s);
+                if (is_mvs<KIND> && needs_std) mvs_to_std(s);
                 mon_pass_two(ms, s, mp);
                 const bool want = mon_need_log(ms, mp);
                 if (mp.kind == SWARM_HIP_MON_LOG_INTERVAL || mp.ej_log || mp.ce_log)
                     if (__any(want)) log_system(lg, s, want);
-                if (KIND == SWARM_HIP_MVS && needs_std) mvs_to_internal(s);
+                if (is_mvs<KIND> && needs_std) mvs_to_internal(s);
             }
             if ((!WHOLE || live) && s.state == SWARM_HIP_ACTIVE && s.t >= dest) s.state = SWARM_HIP_INACTIVE;
             live = live && s.state == SWARM_HIP_ACTIVE;
         }
         // prop.shutdown()
-        if (KIND == SWARM_HIP_MVS) mvs_to_std(s);
+        if (is_mvs<KIND>) mvs_to_std(s);
         if (mine && !stored) store_state(e, gid, s);
     }
     if (ghost) return;
@@ -454,7 +484,11 @@ int launch_generic(const LaunchCtx &c, int integrator) {
     if (layout == 1) return integrator == SWARM_HIP_MVS ? launch_mvs_body(c) : launch_prop_body(c, integrator);
     switch (integrator) {
     case SWARM_HIP_MVS:
-        SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
+        if (c.ip.kepler_compensated) {
+            SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, KIND_MVS_COMPENSATED>(c)));
+        } else {
+            SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_MVS>(c)));
+        }
         break;
     case SWARM_HIP_EULER:
         SWH_DISPATCH_NBOD(c.ens.nbod, return (launch_n<N, SWARM_HIP_EULER>(c)));

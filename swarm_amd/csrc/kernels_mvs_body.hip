@@ -111,10 +111,13 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     // MVSPropagator::drift_step, mvs.hpp:242-256 (mvs_drift); the planets' velocities travel through LDS
     typedef LaneExchange<3> Xchg;
     __shared__ __align__(16) typename Xchg::Row xchg[W];
-    auto drift = [&](const double hby2, const double inv_m0) {
+    // (mvs_momentum / mvs_drift of kernels_generic.hip: with no monitor bound the sum formed for the drift that ends a
+    // step serves the drift that begins the next -- the velocities are the same -- which here also saves an exchange)
+    double mv[3] = {0, 0, 0};
+    auto momentum = [&]() {
 #pragma clang fp contract(off)
         Xchg::put(xchg, lane, v);
-        double mv[3] = {0, 0, 0};
+        mv[0] = mv[1] = mv[2] = 0.0;
 #pragma unroll
         for (int j = 1; j < N; ++j) {
             double vj[3];
@@ -123,6 +126,9 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             for (int c = 0; c < 3; c++) mv[c] = __builtin_fma(m[j], vj[c], mv[c]);
         }
         Xchg::done();
+    };
+    auto drift = [&](const double hby2, const double inv_m0) {
+#pragma clang fp contract(off)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double shift = (mv[c] * hby2) * inv_m0;
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
         // prop.init()
         to_internal(mine);
         planet_forces(acc);
+        momentum();
         // Every lane walks through every step of the slowest system of its wave (the exchange needs all lanes); the
         // lanes of a finished or idle system take steps of h = 0, which leave their registers as they are.
         for (int iter = 0; iter < ip.max_iterations && __any(live); iter++) {
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             }
             // MVSPropagator::advance, mvs.hpp:260-293
             const double hby2 = live ? 0.5 * fmin(max_timestep, ip.time_step) : 0.0;
+            if (EJ) momentum(); // a monitor may have taken the system through standard coordinates
             drift(hby2, inv_m0);
 #pragma unroll
             for (int c = 0; c < 3; c++) v[c] = __builtin_fma(hby2, acc[c], v[c]);
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
             planet_forces(acc);
 #pragma unroll
             for (int c = 0; c < 3; c++) v[c] = __builtin_fma(hby2, acc[c], v[c]);
+            momentum();
             drift(hby2, inv_m0);
             t += 2.0 * hby2;
             if (live) steps++;
