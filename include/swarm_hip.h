@@ -251,6 +251,20 @@ int swarm_hip_event_create(void **event);
 int swarm_hip_event_record(void *event, void *stream);
 int swarm_hip_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises stop */
 int swarm_hip_event_destroy(void *event);
+int swarm_hip_event_synchronize(void *event);
+/* ---- overlapping the log flush with the next launch ---------------------------------------- */
+/* The reference flushes the device log after every launch with a synchronous copy
+ * (gpulog::copy, swarm/log/gpulog/bits/gpulog_log.h:343-394, called by log::manager::flush,
+ * swarm/log/logmanager.cpp:67-87).  With two device logs a host can do the same protocol while the
+ * next launch runs: launch k fills log A; an event recorded behind it; a second stream waits for
+ * that event and copies A's used bytes into page-locked memory while launch k+1 fills log B.
+ * These four calls are all it needs: a stream that is not ordered against the NULL stream,
+ * stream-waits-for-event, an asynchronous D2H copy (`host` must be page-locked to overlap), and
+ * (above) swarm_hip_event_synchronize. */
+int swarm_hip_stream_create(void **stream);
+int swarm_hip_stream_destroy(void *stream);
+int swarm_hip_stream_wait_event(void *stream, void *event);
+int swarm_hip_memcpy_d2h_async(void *host, const void *d_ptr, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

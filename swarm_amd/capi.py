@@ -57,6 +57,8 @@ SYMBOLS = [
     "swarm_hip_memcpy_d2h", "swarm_hip_memcpy_h2d", "swarm_hip_synchronize", "swarm_hip_host_alloc",
     "swarm_hip_host_free", "swarm_hip_event_create",
     "swarm_hip_event_record", "swarm_hip_event_elapsed_ms", "swarm_hip_event_destroy",
+    "swarm_hip_event_synchronize", "swarm_hip_stream_create", "swarm_hip_stream_destroy",
+    "swarm_hip_stream_wait_event", "swarm_hip_memcpy_d2h_async",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -99,6 +101,11 @@ lib.swarm_hip_event_create.argtypes = [C.POINTER(C.c_void_p)]
 lib.swarm_hip_event_record.argtypes = [C.c_void_p, C.c_void_p]
 lib.swarm_hip_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
 lib.swarm_hip_event_destroy.argtypes = [C.c_void_p]
+lib.swarm_hip_event_synchronize.argtypes = [C.c_void_p]
+lib.swarm_hip_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+lib.swarm_hip_stream_destroy.argtypes = [C.c_void_p]
+lib.swarm_hip_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+lib.swarm_hip_memcpy_d2h_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
 
 
 def check(rc):

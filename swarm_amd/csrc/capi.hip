@@ -1041,5 +1041,37 @@ int swarm_hip_event_destroy(void *event) {
     HIP_TRY(hipEventDestroy((hipEvent_t)event));
     return SWARM_HIP_OK;
 }
+int swarm_hip_event_synchronize(void *event) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return SWARM_HIP_OK;
+}
+// ---- a second stream for the log flush ------------------------------------------
+int swarm_hip_stream_create(void **stream) {
+    if (!stream) {
+        set_error("stream_create: NULL out pointer");
+        return SWARM_HIP_EINVAL;
+    }
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); // no implicit ordering against the NULL stream
+    *stream = (void *)st;
+    return SWARM_HIP_OK;
+}
+int swarm_hip_stream_destroy(void *stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_stream_wait_event(void *stream, void *event) {
+    if (!event) {
+        set_error("stream_wait_event: NULL event");
+        return SWARM_HIP_EINVAL;
+    }
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return SWARM_HIP_OK;
+}
+int swarm_hip_memcpy_d2h_async(void *host, const void *d_ptr, size_t bytes, void *stream) {
+    if (int rc = check_copy("memcpy_d2h_async", host, d_ptr, bytes)) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(host, d_ptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SWARM_HIP_OK;
+}
 
 } // extern "C"

@@ -56,6 +56,9 @@ namespace gpu {
 class integrator : public swarm::integrator {
 protected:
     swarm_hip_ensemble_t _dens; // device wave-chunk image, owned
+    swarm_hip_ensemble_t _view; // a run of wave chunks of _dens (core_integrate with log_batches)
+    const swarm_hip_ensemble_t *_launch_ens; // what launch_integrator() works on: &_dens, or &_view
+    int _log_batches; // launches per attempt with a two-log manager (`log_batches`, not a reference key)
     void *_stream;
     int _active_count; // ACTIVE systems as counted after the last launch of the attempt loop; 0 = not known
     void release_device();

@@ -55,25 +55,47 @@ std::string run_printf(const char *record);
 int replay_printf(std::ostream &out, const char *buffer, size_t bytes);
 
 // log::manager, logmanager.hpp / logmanager.cpp:37-87
+// `log_buffers=2` (no reference key; default 1 = the reference's protocol, one synchronous copy after every launch):
+// two device logs and two page-locked host areas; flush_async() starts the copy of the log the launches so far have
+// filled on a second stream and hands the next launch the other log, so that the copy runs while that launch computes.
+// The writer receives the same records (their order in the stream is free in the reference too).
 class manager {
     Pwriter log_writer;
-    uint8_t *d_buf;
-    int32_t *d_cursor;
+    int nbuf, cur;
+    uint8_t *d_buf[2];
+    int32_t *d_cursor[2];
     int capacity;
-    uint8_t *host; // pinned, `capacity` bytes
+    uint8_t *host[2]; // pinned, `capacity` bytes each
     long long _dropped;
+    // asynchronous flush
+    void *copy_stream, *ev_launch, *ev_copy[2];
+    int32_t *cursor_image; // pinned int32[4]
+    struct pending_t {
+        bool in_flight;
+        int32_t used, dropped, nprintf;
+    } pending[2];
+    bool dirty[2]; // the log's device cursor still holds the count of a copy that was started
+    void process(int i, int32_t used, int32_t dropped, int32_t nprintf);
+    void finish(int i);
+
 public:
-    manager() : d_buf(0), d_cursor(0), capacity(0), host(0), _dropped(0) {}
+    manager();
     ~manager();
     // default 50 MiB each, logmanager.hpp:67
     void init(const config &cfg, int host_buffer_size = 50 * 1024 * 1024, int device_buffer_size = 50 * 1024 * 1024);
     // the default log: null writer, no buffers (logmanager.cpp:37-47)
     static std::shared_ptr<manager> &default_log();
-    swarm_hip_log_t get_gpulog() const { swarm_hip_log_t l = {d_buf, d_cursor, capacity}; return l; }
+    // the log the next launch appends to
+    swarm_hip_log_t get_gpulog() const { swarm_hip_log_t l = {d_buf[cur], d_cursor[cur], capacity}; return l; }
     writer *get_writer() const { return log_writer.get(); }
     long long dropped() const { return _dropped; }
-    // flush: D2H copy of the used bytes, clear the device cursor, writer.process (logmanager.cpp:67-87)
+    bool overlapping() const { return nbuf == 2 && d_buf[0]; }
+    // flush: D2H copy of the used bytes, clear the device cursor, writer.process (logmanager.cpp:67-87); also
+    // completes the copies flush_async started.  The launch stream must have drained.
     void flush();
+    // start flushing what the launches enqueued on `launch_stream` so far have logged and switch logs; returns when
+    // those launches have finished and the log that is current from now on has been handed to the writer
+    void flush_async(void *launch_stream);
 };
 typedef std::shared_ptr<manager> Pmanager;
 

@@ -82,19 +82,43 @@ static writer_plugin_initializer<null_writer> null_writer_plugin("null", "This i
 static writer_plugin_initializer<host_array_writer> host_array_writer_plugin("host_array", "Keeps the log in host memory");
 static writer_plugin_initializer<binary_writer> binary_writer_plugin("binary", "This is the binary writer");
 
+manager::manager() : nbuf(1), cur(0), capacity(0), _dropped(0), copy_stream(0), ev_launch(0), cursor_image(0) {
+    for (int i = 0; i < 2; i++) {
+        d_buf[i] = 0, d_cursor[i] = 0, host[i] = 0, ev_copy[i] = 0, dirty[i] = false;
+        pending[i].in_flight = false;
+    }
+}
 manager::~manager() {
-    if (d_buf) swarm_hip_free(d_buf);
-    if (d_cursor) swarm_hip_free(d_cursor);
-    if (host) swarm_hip_host_free(host);
+    if (copy_stream) {
+        swarm_hip_synchronize(copy_stream);
+        swarm_hip_stream_destroy(copy_stream);
+    }
+    if (ev_launch) swarm_hip_event_destroy(ev_launch);
+    if (cursor_image) swarm_hip_host_free(cursor_image);
+    for (int i = 0; i < 2; i++) {
+        if (ev_copy[i]) swarm_hip_event_destroy(ev_copy[i]);
+        if (d_buf[i]) swarm_hip_free(d_buf[i]);
+        if (d_cursor[i]) swarm_hip_free(d_cursor[i]);
+        if (host[i]) swarm_hip_host_free(host[i]);
+    }
 }
 void manager::init(const config &cfg, int, int device_buffer_size) {
     log_writer.reset(writer::create(cfg));
     if (dynamic_cast<null_writer *>(log_writer.get())) return; // null sink: no device buffer
     capacity = device_buffer_size;
-    hipErrCheck(swarm_hip_malloc((void **)&d_buf, (size_t)capacity));
-    hipErrCheck(swarm_hip_malloc((void **)&d_cursor, 16));
-    hipErrCheck(swarm_hip_host_alloc((void **)&host, (size_t)capacity));
-    hipErrCheck(swarm_hip_memset(d_cursor, 0, 16, 0));
+    nbuf = cfg.optional("log_buffers", 1) == 2 ? 2 : 1; // not a reference key
+    for (int i = 0; i < nbuf; i++) {
+        hipErrCheck(swarm_hip_malloc((void **)&d_buf[i], (size_t)capacity));
+        hipErrCheck(swarm_hip_malloc((void **)&d_cursor[i], 16));
+        hipErrCheck(swarm_hip_host_alloc((void **)&host[i], (size_t)capacity));
+        hipErrCheck(swarm_hip_memset(d_cursor[i], 0, 16, 0));
+    }
+    if (nbuf == 2) {
+        hipErrCheck(swarm_hip_stream_create(&copy_stream));
+        hipErrCheck(swarm_hip_event_create(&ev_launch));
+        for (int i = 0; i < 2; i++) hipErrCheck(swarm_hip_event_create(&ev_copy[i]));
+        hipErrCheck(swarm_hip_host_alloc((void **)&cursor_image, 16));
+    }
     hipErrCheck(swarm_hip_synchronize(0));
 }
 Pmanager &manager::default_log() {
@@ -169,19 +193,58 @@ int replay_printf(std::ostream &out, const char *p, size_t n) {
     return count;
 }
 
-void manager::flush() {
-    if (!d_buf) return;
-    int32_t cur[4] = {0, 0, 0, 0}; // bytes used, dropped, lprintf records, -
-    hipErrCheck(swarm_hip_memcpy_d2h(cur, d_cursor, 16));
-    _dropped += cur[1];
-    if (cur[0] > 0) {
-        hipErrCheck(swarm_hip_memcpy_d2h(host, d_buf, (size_t)cur[0]));
-        if (cur[2]) replay_printf(std::cerr, (const char *)host, (size_t)cur[0]); // logmanager.cpp:83
-        log_writer->process((const char *)host, (size_t)cur[0]);
+// what manager::flush does with the host copy (logmanager.cpp:79-86)
+void manager::process(int i, int32_t used, int32_t dropped, int32_t nprintf) {
+    _dropped += dropped;
+    if (used > 0) {
+        if (nprintf) replay_printf(std::cerr, (const char *)host[i], (size_t)used); // logmanager.cpp:83
+        log_writer->process((const char *)host[i], (size_t)used);
     }
-    if (cur[0] || cur[1]) {
-        hipErrCheck(swarm_hip_memset(d_cursor, 0, 16, 0));
-        hipErrCheck(swarm_hip_synchronize(0));
+}
+void manager::finish(int i) {
+    if (!pending[i].in_flight) return;
+    hipErrCheck(swarm_hip_event_synchronize(ev_copy[i]));
+    pending[i].in_flight = false;
+    process(i, pending[i].used, pending[i].dropped, pending[i].nprintf);
+}
+void manager::flush() {
+    if (!d_buf[0]) return;
+    for (int i = 0; i < nbuf; i++) {
+        finish(i);
+        if (dirty[i]) {
+            hipErrCheck(swarm_hip_memset(d_cursor[i], 0, 16, 0));
+            dirty[i] = false;
+        }
+    }
+    int32_t c[4] = {0, 0, 0, 0}; // bytes used, dropped, lprintf records, -
+    hipErrCheck(swarm_hip_memcpy_d2h(c, d_cursor[cur], 16));
+    if (c[0] > 0) hipErrCheck(swarm_hip_memcpy_d2h(host[cur], d_buf[cur], (size_t)c[0]));
+    process(cur, c[0], c[1], c[2]);
+    if (c[0] || c[1]) hipErrCheck(swarm_hip_memset(d_cursor[cur], 0, 16, 0));
+    hipErrCheck(swarm_hip_synchronize(0));
+}
+void manager::flush_async(void *launch_stream) {
+    if (!overlapping()) {
+        if (launch_stream) hipErrCheck(swarm_hip_synchronize(launch_stream));
+        flush();
+        return;
+    }
+    const int i = cur;
+    // the cursor travels on the LAUNCH stream, right behind the kernels: the host learns it the moment they finish,
+    // while the previous log's copy is still in flight on the copy stream, and queues this log's copy behind it
+    hipErrCheck(swarm_hip_memcpy_d2h_async(cursor_image, d_cursor[i], 16, launch_stream));
+    hipErrCheck(swarm_hip_event_record(ev_launch, launch_stream));
+    hipErrCheck(swarm_hip_event_synchronize(ev_launch));
+    pending_t p = {true, cursor_image[0], cursor_image[1], cursor_image[2]};
+    if (p.used > 0) hipErrCheck(swarm_hip_memcpy_d2h_async(host[i], d_buf[i], (size_t)p.used, copy_stream));
+    hipErrCheck(swarm_hip_event_record(ev_copy[i], copy_stream));
+    pending[i] = p;
+    dirty[i] = p.used || p.dropped;
+    cur = 1 - i;
+    finish(cur);
+    if (dirty[cur]) { // cleared on the launch stream, ahead of the launch that appends to it next
+        hipErrCheck(swarm_hip_memset(d_cursor[cur], 0, 16, launch_stream));
+        dirty[cur] = false;
     }
 }
 
@@ -232,7 +295,12 @@ Pintegrator integrator::create(const config &cfg) {
 // ---- gpu::integrator -------------------------------------------------------------------------
 namespace gpu {
 
-integrator::integrator(const config &cfg) : swarm::integrator(cfg), _stream(0), _active_count(0) { std::memset(&_dens, 0, sizeof(_dens)); }
+integrator::integrator(const config &cfg) : swarm::integrator(cfg), _stream(0), _active_count(0) {
+    std::memset(&_dens, 0, sizeof(_dens));
+    _view = _dens;
+    _launch_ens = &_dens;
+    _log_batches = std::max(1, cfg.optional("log_batches", 1));
+}
 integrator::~integrator() { release_device(); }
 void integrator::release_device() {
     if (_dens.body) swarm_hip_free(_dens.body);
@@ -267,15 +335,38 @@ void integrator::download_ensemble() {
 int integrator::core_integrate() {
     int attempts = 0;
     _active_count = 0;
+    // `log_batches` with a two-log manager: every attempt as that many launches over consecutive runs of wave chunks
+    // (a run of chunks is a contiguous range of each device buffer), the flush of one batch's log overlapping the next
+    // batch's launch.  Every system is still launched once per attempt: same records, same counts.
+    const bool overlap = _logman->overlapping();
+    const long long nchunk = swarm_hip_nchunk(_dens.nsys);
+    const int nb = (int)std::max(1LL, std::min((long long)(overlap ? _log_batches : 1), nchunk));
     for (int i = 0; i < _max_attempts; i++) {
-        launch_integrator(); // hands _active_count on as swarm_hip_launch_t::active_hint
-        _logman->flush();
+        for (int k = 0; k < nb; k++) {
+            if (nb > 1) {
+                const long long c0 = nchunk * k / nb, c1 = nchunk * (k + 1) / nb;
+                _view = _dens;
+                _view.nsys = (int32_t)(std::min((long long)_dens.nsys, c1 * SWARM_HIP_CHUNK) - c0 * SWARM_HIP_CHUNK);
+                _view.body = _dens.body + c0 * _dens.nbod * (7 + _dens.nbattr) * SWARM_HIP_CHUNK;
+                _view.sysd = _dens.sysd + c0 * (1 + _dens.nsattr) * SWARM_HIP_CHUNK;
+                _view.sysi = _dens.sysi + c0 * 2 * SWARM_HIP_CHUNK;
+                _launch_ens = &_view;
+                _active_count = 0;
+            }
+            launch_integrator(); // hands _active_count on as swarm_hip_launch_t::active_hint
+            _launch_ens = &_dens;
+            if (overlap)
+                _logman->flush_async(_stream);
+            else
+                _logman->flush();
+        }
         attempts++;
         int32_t n = 0;
         hipErrCheck(swarm_hip_count_active(&_dens, _stream, &n));
         if (n == 0) break;
         _active_count = n;
     }
+    if (overlap) _logman->flush();
     _active_count = 0;
     return attempts;
 }
@@ -362,7 +453,7 @@ public:
         a.log = _logman->get_gpulog();
         a.stream = _stream;
         a.active_hint = _active_count;
-        hipErrCheck(swarm_hip_launch_integrator(&_dens, &a));
+        hipErrCheck(swarm_hip_launch_integrator(_launch_ens, &a));
     }
 };
 

@@ -177,6 +177,20 @@ class DeviceEnsemble:
     def ref(self):
         return C.byref(self.c)
 
+    def chunk_view(self, c0, c1):
+        """The systems of wave chunks [c0, c1) as an ensemble of their own on borrowed pointers: a run of chunks is
+        one contiguous byte range of each of the three buffers (include/swarm_hip.h), which is also what a multi-GPU
+        shard is (parallel.py).  System ids travel with the systems (sysi)."""
+        nchunk = int(capi.lib.swarm_hip_nchunk(self.nsys))
+        assert 0 <= c0 < c1 <= nchunk, (c0, c1, nchunk)
+        nsys = min(self.nsys, c1 * capi.CHUNK) - c0 * capi.CHUNK
+        W = capi.CHUNK
+        off = (c0 * self.nbod * (7 + self.nbattr) * W * 8, c0 * (1 + self.nsattr) * W * 8, c0 * 2 * W * 4)
+        v = DeviceEnsemble(nsys, self.nbod, self.nbattr, self.nsattr,
+                           pointers=[self.c.body + off[0], self.c.sysd + off[1], self.c.sysi + off[2]])
+        v.first_system = c0 * W
+        return v
+
     def upload(self, h):
         assert (h.nsys, h.nbod) == (self.nsys, self.nbod)
         arrs = [np.ascontiguousarray(a) for a in (h.pos, h.vel, h.mass, h.time, h.state, h.id,

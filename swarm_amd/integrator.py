@@ -114,32 +114,82 @@ class BinaryWriter:
 class LogManager:
     """log::manager (swarm/log/logmanager.cpp:50-87): owns the device event buffer; flush() copies
     the used bytes to the host and clears the device cursor.  The default log has 0-byte buffers
-    and a null writer (logmanager.cpp:37-47)."""
+    and a null writer (logmanager.cpp:37-47).
 
-    def __init__(self, device_bytes=0, writer=None):
+    buffers=2 (no counterpart in the reference, whose flush is one synchronous copy after every launch): two device
+    logs and two page-locked staging areas.  flush_async() starts the copy of the log the last launch filled on a
+    second stream and hands the next launch the other log, so that the copy runs while that launch computes; the
+    writer sees the same records (their order in the stream is free in the reference too: one atomic cursor)."""
+
+    def __init__(self, device_bytes=0, writer=None, buffers=1):
         self.capacity = int(device_bytes)
         self.writer = writer  # callable(bytes) or None (= null writer)
-        self.buf = DeviceBuffer(self.capacity) if self.capacity else None
-        self.cursor = DeviceBuffer(16) if self.capacity else None   # int32[4]: used, dropped, lprintf records, -
-        if self.cursor:
-            self.cursor.zero()
+        self.nbuf = int(buffers) if self.capacity else 1
+        assert self.nbuf in (1, 2)
+        self.bufs = [DeviceBuffer(self.capacity) for _ in range(self.nbuf)] if self.capacity else []
+        self.cursors = [DeviceBuffer(16) for _ in range(self.nbuf)] if self.capacity else []  # int32[4]: used, dropped, lprintf records, -
+        for c in self.cursors:
+            c.zero()
+        self.cur = 0                # the log the next launch appends to
         self.host = bytearray()
         self.replay_printf = True   # lprintf lines go to stderr at every flush (logmanager.cpp:79-83)
         self.printf_count = 0
         self.dropped = 0
         self.bytes_flushed = 0
-        # pinned staging buffer: the D2H copy of a flush runs at PCIe speed
-        self._pinned = C.c_void_p()
-        if self.capacity:
-            capi.check(capi.lib.swarm_hip_host_alloc(C.byref(self._pinned), self.capacity))
-            self._stage = np.ctypeslib.as_array(C.cast(self._pinned, C.POINTER(C.c_uint8)), shape=(self.capacity,))
+        # pinned staging buffers: the D2H copy of a flush runs at PCIe speed
+        self._pinneds, self._stages = [], []
+        for _ in range(self.nbuf if self.capacity else 0):
+            p = C.c_void_p()
+            capi.check(capi.lib.swarm_hip_host_alloc(C.byref(p), self.capacity))
+            self._pinneds.append(p)
+            self._stages.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.capacity,)))
+        # asynchronous flush: copy stream, one event behind the launch, one behind each copy, a pinned cursor image
+        self._copy_stream = C.c_void_p()
+        self._pending = [None] * self.nbuf     # (used, dropped, nprintf) of a copy in flight, per log
+        self._dirty = [False] * self.nbuf      # the log's device cursor still holds the count of a copy that was started
+        self._ev_launch = C.c_void_p()
+        self._ev_copy = [C.c_void_p() for _ in range(self.nbuf)]
+        self._pinned_cur = C.c_void_p()
+        if self.nbuf == 2:
+            capi.check(capi.lib.swarm_hip_stream_create(C.byref(self._copy_stream)))
+            capi.check(capi.lib.swarm_hip_event_create(C.byref(self._ev_launch)))
+            for e in self._ev_copy:
+                capi.check(capi.lib.swarm_hip_event_create(C.byref(e)))
+            capi.check(capi.lib.swarm_hip_host_alloc(C.byref(self._pinned_cur), 16))
+            self._cur_img = np.ctypeslib.as_array(C.cast(self._pinned_cur, C.POINTER(C.c_int32)), shape=(4,))
+
+    # the single-log names, for callers that look at the device log directly
+    @property
+    def buf(self):
+        return self.bufs[self.cur] if self.bufs else None
+
+    @property
+    def cursor(self):
+        return self.cursors[self.cur] if self.cursors else None
+
+    @property
+    def _pinned(self):
+        return self._pinneds[self.cur] if self._pinneds else C.c_void_p()
+
+    @property
+    def _stage(self):
+        return self._stages[self.cur] if self._stages else None
 
     def __del__(self):
         try:
-            if self._pinned:
-                self._stage = None
-                capi.lib.swarm_hip_host_free(self._pinned)
-                self._pinned = C.c_void_p()
+            L = capi.lib
+            if self._copy_stream:
+                L.swarm_hip_synchronize(self._copy_stream)
+                L.swarm_hip_stream_destroy(self._copy_stream)
+                self._copy_stream = C.c_void_p()
+                for e in [self._ev_launch] + self._ev_copy:
+                    L.swarm_hip_event_destroy(e)
+                self._cur_img = None
+                L.swarm_hip_host_free(self._pinned_cur)
+            self._stages = []
+            for p in self._pinneds:
+                L.swarm_hip_host_free(p)
+            self._pinneds = []
         except Exception:
             pass
 
@@ -164,28 +214,77 @@ class LogManager:
     def struct(self):
         if not self.capacity:
             return capi.LogStruct(None, None, 0)
-        return capi.LogStruct(self.buf.ptr, self.cursor.ptr, self.capacity)
+        return capi.LogStruct(self.bufs[self.cur].ptr, self.cursors[self.cur].ptr, self.capacity)
 
-    def flush(self):
-        if not self.capacity:
-            return
-        cur = self.cursor.to_host(np.int32)
-        used, dropped, nprintf = int(cur[0]), int(cur[1]), int(cur[2])
+    def _process(self, stage, used, dropped, nprintf):
+        """what manager::flush does with the host copy (logmanager.cpp:79-86): replay the printf records, hand the
+        bytes to the writer"""
         self.dropped += dropped
         if used:
-            capi.check(capi.lib.swarm_hip_memcpy_d2h(self._pinned, self.buf.ptr, used))
             self.bytes_flushed += used
             if self.replay_printf and nprintf:   # logmanager.cpp:83: replay_printf(std::cerr, hlog)
-                self.printf_count += gpulog.replay_printf(sys.stderr, self._stage[:used].tobytes())
+                self.printf_count += gpulog.replay_printf(sys.stderr, stage[:used].tobytes())
             if self.writer == "host":
-                self.host += memoryview(self._stage[:used])
+                self.host += memoryview(stage[:used])
             elif self.writer == "count":
                 pass  # bytes_flushed only: measures the flush protocol without a sink
             elif self.writer is not None:
-                self.writer.process(self._stage[:used].tobytes())
-        if used or dropped:
-            self.cursor.zero()
+                self.writer.process(stage[:used].tobytes())
 
+    def _finish(self, i):
+        """wait for the copy of log i that flush_async started, and process its bytes"""
+        if self._pending[i] is not None:
+            capi.check(capi.lib.swarm_hip_event_synchronize(self._ev_copy[i]))
+            pend, self._pending[i] = self._pending[i], None
+            self._process(self._stages[i], *pend)
+
+    def flush(self):
+        """Synchronous flush (the reference's protocol).  The launch stream must have drained."""
+        if not self.capacity:
+            return
+        for i in range(self.nbuf):
+            self._finish(i)
+            if self._dirty[i]:
+                self.cursors[i].zero()
+                self._dirty[i] = False
+        cur = self.cursors[self.cur].to_host(np.int32)
+        used, dropped, nprintf = int(cur[0]), int(cur[1]), int(cur[2])
+        if used:
+            capi.check(capi.lib.swarm_hip_memcpy_d2h(self._pinneds[self.cur], self.bufs[self.cur].ptr, used))
+        self._process(self._stages[self.cur], used, dropped, nprintf)
+        if used or dropped:
+            self.cursors[self.cur].zero()
+
+    def flush_async(self, launch_stream=None):
+        """Start flushing the log that the launches enqueued so far on `launch_stream` have filled, and switch to the
+        other log: the next launch may be enqueued as soon as this returns and runs while the copy is in flight.
+        Returns after (1) those launches have finished -- the copy's length is the cursor they leave -- and (2) the
+        previous copy out of the log that is current from now on has been handed to the writer.  Nothing is lost when
+        a copy overlaps a running kernel: the kernel appends to the other log."""
+        if self.nbuf != 2:
+            if launch_stream:
+                capi.check(capi.lib.swarm_hip_synchronize(launch_stream))
+            return self.flush()
+        L, i, cs = capi.lib, self.cur, self._copy_stream
+        # the cursor travels on the LAUNCH stream, right behind the kernels: the host learns it the moment they finish,
+        # while the previous log's copy is still in flight on the copy stream, and queues this log's copy behind that
+        # one without a gap
+        capi.check(L.swarm_hip_memcpy_d2h_async(self._pinned_cur, self.cursors[i].ptr, 16, launch_stream))
+        capi.check(L.swarm_hip_event_record(self._ev_launch, launch_stream))
+        capi.check(L.swarm_hip_event_synchronize(self._ev_launch))
+        used, dropped, nprintf = int(self._cur_img[0]), int(self._cur_img[1]), int(self._cur_img[2])
+        # (the kernels are known to have finished: the copy needs no stream-side wait, and nothing but the copy and
+        # its event goes onto the copy stream, so that successive copies follow each other without a gap)
+        if used:
+            capi.check(L.swarm_hip_memcpy_d2h_async(self._pinneds[i], self.bufs[i].ptr, used, cs))
+        capi.check(L.swarm_hip_event_record(self._ev_copy[i], cs))
+        self._pending[i] = (used, dropped, nprintf)
+        self._dirty[i] = bool(used or dropped)
+        self.cur = 1 - i
+        self._finish(self.cur)
+        if self._dirty[self.cur]:   # cleared on the launch stream, ahead of the launch that appends to it next
+            capi.check(L.swarm_hip_memset(self.cursors[self.cur].ptr, 0, 16, launch_stream))
+            self._dirty[self.cur] = False
 
 
 class Integrator:
@@ -270,6 +369,9 @@ class GpuIntegrator(Integrator):
             a.kepler_compensated = int(cfg.optional("kepler_compensated", 0))
         a.lane_mode = cfg.optional("lane_mode", 0)                     # not a reference key: 0 auto, 1 per system, 2 per body
         self.use_active_hint = bool(cfg.optional("active_hint", 1))   # not a reference key: 0 = never pass the count on
+        # not a reference key: with a two-log manager (LogManager(..., buffers=2)) every attempt of the launch loop runs
+        # as this many launches over consecutive runs of wave chunks, the flush of one overlapping the launch of the next
+        self.log_batches = max(1, int(cfg.optional("log_batches", 1)))
         self.args = a
         self.steps_accepted = None
         self.steps_attempted = None
@@ -320,36 +422,54 @@ class GpuIntegrator(Integrator):
     def flush_log(self):
         self._logman.flush()
 
-    def launch_integrator(self):
+    def launch_integrator(self, view=None):
+        """one launch over the whole device ensemble, or over `view` = self._dens.chunk_view(c0, c1)"""
         a = self.args
         a.destination_time = self._destination_time
         a.max_iterations = self._max_iterations
         a.log = self._logman.struct()
-        a.d_steps_accepted = self.steps_accepted.ptr if self.steps_accepted else None
-        a.d_steps_attempted = self.steps_attempted.ptr if self.steps_attempted else None
+        first = view.first_system if view is not None else 0       # the step counters are indexed by system
+        a.d_steps_accepted = self.steps_accepted.ptr + 8 * first if self.steps_accepted else None
+        a.d_steps_attempted = self.steps_attempted.ptr + 8 * first if self.steps_attempted else None
         a.stream = self.stream
         # the count the attempt loop made after the previous launch (integrator.cpp:113), if nothing has touched the
         # states since: lets the library pick the kernel layout by ACTIVE systems and pack them into dense wavefronts
-        a.active_hint = (self._dens.last_active_count or 0) if self.use_active_hint else 0
+        a.active_hint = (self._dens.last_active_count or 0) if (self.use_active_hint and view is None) else 0
         if self.name in ("hermite", "irk2"):
             a.monitor = capi.MON_MCE_STAT if self._dens.nbattr >= 3 else capi.MON_EJECTION
             if a.monitor == capi.MON_MCE_STAT and "nbod" in self.cfg and int(self.cfg["nbod"]) != self._dens.nbod:
                 raise runtime_error("mce_stat: nbod=%s in the configuration but the ensemble has %d bodies"
                                     % (self.cfg["nbod"], self._dens.nbod))
-        capi.check(capi.lib.swarm_hip_launch_integrator(self._dens.ref, C.byref(a)))
+        capi.check(capi.lib.swarm_hip_launch_integrator((view or self._dens).ref, C.byref(a)))
         self._dens.last_active_count = None     # the launch changes states
 
     def core_integrate(self):
         """The device-resident part of integrate(): attempt loop without host<->device copies."""
         attempts = 0
+        overlap = self._logman.nbuf == 2
+        views = [None]
+        if overlap and self.log_batches > 1:
+            # the systems of an attempt in `log_batches` launches over consecutive runs of wave chunks: every system
+            # is still launched once per attempt (same records, same counts), and the flush of one batch's log
+            # overlaps the next batch's launch.  One launch per attempt otherwise.
+            nchunk = int(capi.lib.swarm_hip_nchunk(self._dens.nsys))
+            nb = min(self.log_batches, nchunk)
+            cuts = [nchunk * k // nb for k in range(nb + 1)]
+            views = [self._dens.chunk_view(cuts[k], cuts[k + 1]) for k in range(nb)]
         for _ in range(self._max_attempts):
-            self.launch_integrator()
-            if self.stream:     # the flush reads and clears the cursor on the null stream: let the launch stream drain first
-                capi.check(capi.lib.swarm_hip_synchronize(self.stream))
-            self._logman.flush()
+            for v in views:
+                self.launch_integrator(v)
+                if overlap:     # the next launch (batch, or attempt) goes to the other log while this one is copied
+                    self._logman.flush_async(self.stream)
+                else:
+                    if self.stream:     # the flush reads and clears the cursor on the null stream: let the launch stream drain first
+                        capi.check(capi.lib.swarm_hip_synchronize(self.stream))
+                    self._logman.flush()
             attempts += 1
             if self._dens.count_active(self.stream) == 0:
                 break
+        if overlap:
+            self._logman.flush()     # the copies still in flight, and whatever the current log holds (nothing)
         return attempts
 
     def integrate(self):

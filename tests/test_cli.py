@@ -313,6 +313,23 @@ def test_reference_bdb_script_through_the_gpu_path(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_log_manager_writes_the_same_sorted_log_file(tmp_path):
+    """`log_buffers=2` (+ `log_batches`) in the C++ host (log::manager::flush_async, DESIGN 3.12): the copy of one log
+    overlaps the next launch.  The binary writer sorts its file by (time, system) on close, so the files of the
+    reference's protocol and of the overlapped one must be the same bytes; so must the final ensembles.  1000 systems
+    and max_iterations=9 make it a loop of many launches over 16 wave chunks."""
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["log_buffers=2"]), ("batched", ["log_buffers=2", "log_batches=5"])):
+        log, ens = tmp_path / (tag + ".bin"), tmp_path / (tag + ".ens")
+        run("integrate", "integrator=hermite_adap_log", "time_step_factor=0.017", "min_time_step=1e-5", "log_interval=0.5",
+            "nsys=1000", "nbod=4", "destination_time=12", "max_iterations=9", "log_writer=binary", "log_output=%s" % log,
+            "-o", ens, *extra)
+        outs[tag] = (open(log, "rb").read(), open(ens, "rb").read())
+    assert len(outs["one"][0]) > 96 + 1000 * 25 * 288
+    assert outs["one"] == outs["two"] == outs["batched"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nbod", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])     # every golden pair the reference ships
 def test_reference_hermite_cpu_cfg_reproduces_goldens(nbod):
     """test/integrators/Hermite_CPU.cfg is the configuration the golden outputs were generated with

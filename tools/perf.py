@@ -264,6 +264,45 @@ def measure(workload, nsys=None, nbod=None, T=None, reps=3, block=0, lane_mode=0
 
 
 
+def measure_flush(workload, batches=0, nsys=None, nbod=None, T=None, reps=5, capacity=None):
+    """Host-to-host time of the launch loop WITH its log flushes (core_integrate: launches, flush after each, active
+    count; ensemble resident, records into page-locked memory, no sink): batches = 0 is the reference's protocol (one
+    log, a synchronous copy after the launch), batches >= 1 the two-log manager with every attempt split into that
+    many launches over runs of wave chunks.  The same LogManager serves all repetitions and the first
+    one is dropped (page-locked memory is slow the first time it is written).  Median of the rest."""
+    w = dict(WORKLOADS[workload])
+    nsys, nbod, T = nsys or w["nsys"], nbod or w["nbod"], T or w["T"]
+    S.capi.check(S.capi.lib.swarm_hip_init(0))
+    L = S.capi.lib
+    host0 = make_ensemble(w, nsys, nbod)
+    cfg = dict(w["cfg"], integrator=w["integrator"], log_batches=str(max(batches, 1)))
+    cap = capacity or (w["log"] if batches == 0 else (w["log"] // batches + (8 << 20)))
+    lm = S.LogManager(cap, "count", buffers=2 if batches else 1)
+    res = []
+    for rep in range(reps + 1):
+        host = host0.clone()
+        integ = S.Integrator.create(S.config(cfg))
+        integ.set_ensemble(host)
+        integ.set_destination_time(T)
+        integ.set_log_manager(lm)
+        integ.upload_ensemble()
+        lm.bytes_flushed = 0
+        lm.dropped = 0
+        L.swarm_hip_synchronize(None)
+        t0 = time.perf_counter()
+        attempts = integ.core_integrate()
+        L.swarm_hip_synchronize(None)
+        ms = (time.perf_counter() - t0) * 1e3
+        if rep:
+            res.append(dict(ms=ms, log_bytes=lm.bytes_flushed, dropped=lm.dropped, attempts=attempts))
+    res.sort(key=lambda r: r["ms"])
+    out = dict(res[len(res) // 2])
+    out.update(workload=workload, nsys=nsys, nbod=nbod, T=T, batches=batches, log_capacity=cap, reps=reps,
+               ms_min_max=[round(res[0]["ms"], 4), round(res[-1]["ms"], 4)],
+               d2h_GBps=out["log_bytes"] / (out["ms"] * 1e-3) / 1e9)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload", choices=sorted(WORKLOADS))
@@ -279,8 +318,14 @@ def main():
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--warm", action="store_true", help="enqueue the same launch on a copy directly ahead of the timed one")
     ap.add_argument("--sparse", type=int, default=0, help="K > 1: only every K-th system ACTIVE, the others DISABLED; K < 0: every |K|-th wavefront thin (4 ACTIVE), the others full")
+    ap.add_argument("--flush-batches", type=int, default=None,
+                    help="logging workloads: time the launch loop with its flushes instead (0 = one log, synchronous "
+                         "copy; B >= 1 = two logs, B launches per attempt, copies overlapping launches)")
     ap.add_argument("cfg", nargs="*", help="extra key=value configuration pairs")
     a = ap.parse_args()
+    if a.flush_batches is not None:
+        print(json.dumps(measure_flush(a.workload, a.flush_batches, a.nsys, a.nbod, a.T, a.reps)))
+        return
     print(json.dumps(measure(a.workload, a.nsys, a.nbod, a.T, a.reps, a.block, a.lane_mode, a.spread, a.shuffle,
                              a.pinned, not a.no_host_to_host, dict(kv.split("=", 1) for kv in a.cfg), a.warm, a.sparse)))
 
