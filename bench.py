@@ -81,6 +81,17 @@ def secondary_block():
                          "ensemble is enqueued directly ahead of the timed one so that it does not start at an idle clock")
         keep["reproduce"] = "python tools/perf.py %s %s--warm --no-host-to-host --reps 5" % (workload, "--shuffle " if kw.get("shuffle") else "")
         out[tag] = keep
+    # C5's launch loop with its flush (launch, copy of the 396 MB of records into page-locked memory, active count):
+    # the reference's protocol, and the two-log manager with the attempt in four launches
+    fl = {}
+    for name, batches in (("one_log_synchronous_copy_ms", 0), ("two_logs_4_batches_ms", 4)):
+        r = perf.measure_flush("c5", batches, reps=5)
+        fl[name] = round(r["ms"], 4)
+        fl[name.replace("_ms", "_min_max")] = r["ms_min_max"]
+        fl["log_bytes"], fl["dropped"] = r["log_bytes"], r["dropped"]
+    fl["ms_is"] = "host to host around core_integrate(), ensemble resident, median of 5 after one dropped run"
+    fl["reproduce"] = "python tools/perf.py c5 --flush-batches 0|4 --reps 5"
+    out["c5_launch_and_flush"] = fl
     return out
 
 
@@ -259,27 +270,30 @@ def main():
     # energy / ejection statistics: one small all-reduce (sum, max, min) over RCCL
     stats = P.allreduce_stats(*P.local_stats(derr, final.state, steps_accepted=nsys * steps_per_pass * args.steps),
                               dist=dist, device=cdev)
-    gather_ms, gather_ok = None, None
+    gather_ms, gather_ok, gather_error = None, None, None
     if dist is not None:
         # final ensemble gather: a shard is a contiguous run of wave chunks, so ONE gather per device buffer into
         # slices of a preallocated tensor on rank 0 gives the wave-chunk image of the whole ensemble; the senders'
-        # checksums travel in one small all-gather and rank 0 checks every slice against them
-        srcs = [t.to(cdev) for t in (tb, td, ti)]
-        mine = P.buffer_checksums(srcs)
-        sums = torch.empty(world * 3, dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(sums, mine)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        outs = P.gather_to_root(srcs, dist, rank, world)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0:
-            got = torch.stack([P.buffer_checksums(list(o.split(t.numel()))) for o, t in zip(outs, srcs)], dim=1)
-            gather_ok = bool(torch.equal(got.cpu(), sums.reshape(world, 3).cpu()))
-            ids = outs[2].view(torch.int32).reshape(-1, 2, 64)[:, 1, :].reshape(-1).cpu().numpy()
-            gather_ok = gather_ok and bool((ids == np.arange(world * nsys)).all())
-            assert gather_ok, "gathered shards differ from what the ranks sent"
+        # checksums travel in one small all-gather and rank 0 checks every slice against them.  Outside the timed
+        # region: a failure here is reported in the line (gather_verified false + the message), it does not void `value`.
+        try:
+            srcs = [t.to(cdev) for t in (tb, td, ti)]
+            mine = P.buffer_checksums(srcs)
+            sums = torch.empty(world * 3, dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(sums, mine)
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            outs = P.gather_to_root(srcs, dist, rank, world)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                got = torch.stack([P.buffer_checksums(list(o.split(t.numel()))) for o, t in zip(outs, srcs)], dim=1)
+                gather_ok = bool(torch.equal(got.cpu(), sums.reshape(world, 3).cpu()))
+                ids = outs[2].view(torch.int32).reshape(-1, 2, 64)[:, 1, :].reshape(-1).cpu().numpy()
+                gather_ok = gather_ok and bool((ids == np.arange(world * nsys)).all())
+        except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
+            gather_ok, gather_error = False, "%s: %s" % (type(ex).__name__, ex)
 
     total_sys_steps = float(world) * nsys * steps_per_pass * args.steps
     value = total_sys_steps / elapsed
@@ -325,9 +339,11 @@ def main():
         "energy": {"max_rel_err": stats["max_abs_dE_over_E"], "mean_rel_err": stats["mean_abs_dE_over_E"],
                    "n_disabled": int(stats["n_disabled"]), "n_systems": int(stats["nsys"])},
     }
-    if gather_ms is not None:
+    if dist is not None:
         out["gather_ms"] = gather_ms
         out["gather_verified"] = bool(gather_ok)
+        if gather_error:
+            out["gather_error"] = gather_error
         out["gathered_bytes"] = int(world * (tb.numel() + td.numel() + ti.numel()))
         out["exchange"] = "%s: all_reduce x 3 of the statistics, all_gather of 3 checksums, gather of body/sysd/sysi to rank 0" % backend
         out["rccl_ranks"] = world if backend == "nccl" else 0
