@@ -53,3 +53,23 @@ def test_noalloc_rejects_what_it_cannot_hold(gpu):
     assert rc == -1 and b"SWARM_HIP_NOALLOC_MAX_NSYS" in S.capi.lib.swarm_hip_last_error()
     _, d = _ensemble(S, 64, 3, 4)
     assert S.capi.lib.swarm_hip_count_active_noalloc(d.ref, None, None) == -1
+
+
+def test_noalloc_count_on_a_stream_of_its_own(gpu):
+    """the call is asynchronous on the caller's stream: two calls queued back to back on a non-NULL stream (ordered
+    by the stream, as the header asks of calls that share a GPU), the results read after one synchronisation"""
+    S = gpu
+    L = S.capi.lib
+    stream = C.c_void_p()
+    S.capi.check(L.swarm_hip_stream_create(C.byref(stream)))
+    try:
+        (h1, d1), (h2, d2) = _ensemble(S, 2 * 4096 + 5, 3, 11), _ensemble(S, 700, 5, 12)
+        L.swarm_hip_synchronize(None)
+        c1, c2 = S.DeviceBuffer(16), S.DeviceBuffer(16)
+        S.capi.check(L.swarm_hip_count_active_noalloc(d1.ref, c1.ptr, stream))
+        S.capi.check(L.swarm_hip_count_active_noalloc(d2.ref, c2.ptr, stream))
+        S.capi.check(L.swarm_hip_synchronize(stream))
+        assert int(c1.to_host(np.int32)[0]) == int((h1.state == 0).sum())
+        assert int(c2.to_host(np.int32)[0]) == int((h2.state == 0).sum())
+    finally:
+        S.capi.check(L.swarm_hip_stream_destroy(stream))
