@@ -337,8 +337,17 @@ struct StepConsts {
 // CUDA kernel's factored form `pre_pos + (A - B)` (hermite_integrator.hpp:146) always rounds the
 // net correction away (stagnation): measured with the oracle at dt=1e-4, r=1, 1e5 steps it
 // drifts 6.6e-12 in position and conserves energy 10x worse (5.8e-13 vs 4.1e-14) than
-// hermite_cpu, the pinned reference.  Adding the two ~700-ulp parts one after the other keeps the
-// roundings unbiased.  VELOCITY is insensitive to the form (its correction is >> 1 ulp).
+// hermite_cpu, the pinned reference.  Adding the parts one after the other keeps the roundings unbiased.
+// Round 3: EVERY one of the four terms (c1 h^2 a0, -c1 h^2 a1, and the two jerk terms) is added to the position by
+// an fma of its own -- `fma(kj1, j1, fma(-ka, a1, pp))` with pp = fma(kj0, j0, fma(ka, a0, pre_pos)) -- instead of
+// `fma(-ka, a1, pp) + fma(kj1, j1, kj0*j0)`: one operation per coordinate and corrector pass fewer and nine doubles
+// fewer live across the force evaluations (headline 16.83 -> 15.81 ms, 432 -> 414 instructions per step; nbod 6 0.68 ->
+// 0.75 of peak).  Energy conservation is what it was (tools/exp_hermite_energy.py, profiles/r3/hermite_corrector_forms.txt:
+// trivial.py's BasicIntegration case 4.5e-15 against 5.5e-15, the reference's bar is 1e-13; 4096 perturbed systems
+// median 1.74e-14 against 1.68e-14), the distance from hermite_cpu after 1e5 steps 1.1e-12 against 9.0e-13.
+// VELOCITY keeps its single rounding: the correction is summed first and added once.  The same treatment of the
+// velocity (four fmas onto pre_vel) is another 4 % faster (15.14 ms) but puts four roundings of ulp(v) into every
+// step, and BasicIntegration then conserves energy to 2.1e-13 -- beyond the reference's own bar; not taken.
 // `vp` = the velocity the POSITION predictor uses: the reference kernel predicts from the global
 // pos/vel but with its register copy of vel (hermite_integrator.hpp:124-132); the two differ only
 // after a monitor rewrote the system (mce_stat merges).
@@ -353,7 +362,7 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
     // (0.56 -> 0.66 of FP64 peak), nbod 10 384 -> 220 B (0.38 -> 0.48).  (Keeping pp and c0 in LDS instead was tried:
     // the scheduler hoists the reads above the force evaluation and spills more than before, volatile or not.)
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM;
-    double pp[N][3], pv[N][3], c0[N][3], d0[FOLD ? 1 : N][3];
+    double pp[N][3], pv[N][3], d0[FOLD ? 1 : N][3];
 #pragma unroll
     for (int b = 0; b < N; b++)
 #pragma unroll
@@ -363,8 +372,9 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
             pv[b][c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[b][c], a0[b][c]), s.v[b][c]);
             s.p[b][c] = pp[b][c];
             s.v[b][c] = pv[b][c];
-            c0[b][c] = k.kp_j0 * j0[b][c];                        // jerk part, start-of-step term
-            pp[b][c] = __builtin_fma(k.kp_a, a0[b][c], pp[b][c]); // pre_pos + c1*h^2*a0
+            // pre_pos + c1*h^2*a0, then the start-of-step jerk term: every term of the position corrector is added to
+            // the position by an fma of its own
+            pp[b][c] = __builtin_fma(k.kp_j0, j0[b][c], __builtin_fma(k.kp_a, a0[b][c], pp[b][c]));
             const double dd = __builtin_fma(k.kv_a, a0[b][c], k.kv_j0 * j0[b][c]);
             if (FOLD)
                 pv[b][c] = pv[b][c] + dd;
@@ -378,7 +388,7 @@ __device__ __forceinline__ void hermite_step(State<N> &s, const StepConsts &k, c
         for (int b = 0; b < N; b++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                s.p[b][c] = __builtin_fma(-k.kp_a, a1[b][c], pp[b][c]) + __builtin_fma(k.kp_j1, j1[b][c], c0[b][c]);
+                s.p[b][c] = __builtin_fma(k.kp_j1, j1[b][c], __builtin_fma(-k.kp_a, a1[b][c], pp[b][c]));
                 if (FOLD)
                     s.v[b][c] = pv[b][c] + __builtin_fma(-k.kv_a, a1[b][c], k.kv_j1 * j1[b][c]);
                 else

@@ -132,15 +132,14 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
         else if (h != k.h)
             k.set(h);
         const double p_in[3] = {p[0], p[1], p[2]}, v_in[3] = {v[0], v[1], v[2]};
-        double pp[3], pv[3], c0[3], dd0[3];
+        double pp[3], pv[3], dd0[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) { // hermite_step<N>, predictor
             pp[c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[c], a0[c]), v[c]), p[c]);
             pv[c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[c], a0[c]), v[c]);
             p[c] = pp[c];
             v[c] = pv[c];
-            c0[c] = k.kp_j0 * j0[c];
-            pp[c] = __builtin_fma(k.kp_a, a0[c], pp[c]);
+            pp[c] = __builtin_fma(k.kp_j0, j0[c], __builtin_fma(k.kp_a, a0[c], pp[c]));
             dd0[c] = __builtin_fma(k.kv_a, a0[c], k.kv_j0 * j0[c]);
             if (FOLD) pv[c] = pv[c] + dd0[c]; // hermite_step<N>'s form from nbod 9 on
         }
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             forces(a1, j1);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                p[c] = __builtin_fma(-k.kp_a, a1[c], pp[c]) + __builtin_fma(k.kp_j1, j1[c], c0[c]);
+                p[c] = __builtin_fma(k.kp_j1, j1[c], __builtin_fma(-k.kp_a, a1[c], pp[c]));
                 v[c] = FOLD ? pv[c] + __builtin_fma(-k.kv_a, a1[c], k.kv_j1 * j1[c])
                             : pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
             }

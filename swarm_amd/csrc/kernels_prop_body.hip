@@ -176,15 +176,14 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             } else if (KIND == SWARM_HIP_HERMITE_PROP) { // HermitePropagator::advance, hermite_propagator.hpp:106-142
                 h = fmin(ip.time_step, max_timestep);
                 if (h != k.h) k.set(h);
-                double pp[3], pv[3], c0[3], dd0[3];
+                double pp[3], pv[3], dd0[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) { // hermite_step<N>, predictor
                     pp[c] = __builtin_fma(k.h, __builtin_fma(k.hh, __builtin_fma(k.h3, j0[c], a0[c]), v[c]), p[c]);
                     pv[c] = __builtin_fma(k.h, __builtin_fma(k.hh, j0[c], a0[c]), v[c]);
                     np[c] = pp[c];
                     nv[c] = pv[c];
-                    c0[c] = k.kp_j0 * j0[c];
-                    pp[c] = __builtin_fma(k.kp_a, a0[c], pp[c]);
+                    pp[c] = __builtin_fma(k.kp_j0, j0[c], __builtin_fma(k.kp_a, a0[c], pp[c]));
                     dd0[c] = __builtin_fma(k.kv_a, a0[c], k.kv_j0 * j0[c]);
                     if (FOLD) pv[c] = pv[c] + dd0[c];
                 }
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
                     accjerk_body(np, nv, a1, j1);
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        np[c] = __builtin_fma(-k.kp_a, a1[c], pp[c]) + __builtin_fma(k.kp_j1, j1[c], c0[c]);
+                        np[c] = __builtin_fma(k.kp_j1, j1[c], __builtin_fma(-k.kp_a, a1[c], pp[c]));
                         nv[c] = FOLD ? pv[c] + __builtin_fma(-k.kv_a, a1[c], k.kv_j1 * j1[c])
                                      : pv[c] + __builtin_fma(-k.kv_a, a1[c], __builtin_fma(k.kv_j1, j1[c], dd0[c]));
                     }
