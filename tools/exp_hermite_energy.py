@@ -24,24 +24,32 @@ def run(host, T, dt):
     return np.abs((host.calc_total_energy() - e0) / e0)
 
 
+NBODS = ((3, 0.1), (6, 0.1), (3, 1.0))
+
+
 def main():
+    global NBODS
+    if len(sys.argv) > 1 and sys.argv[1] == "--nbod3":
+        NBODS = ((3, 0.1), (3, 1.0))
     S.capi.check(S.capi.lib.swarm_hip_init(0))
     out = {}
     h = S.generate_ensemble(S.config({"nsys": "16", "nbod": "3"}))
     out["basic_integration_max_dE"] = float(run(h, 10.0, 1e-4).max())
-    for nbod in (3, 6):
+    for nbod, s in NBODS:
         e = O.generate(4096, nbod)
         rng = np.random.default_rng(11)
         e.pos[:, 1:, :] *= 1.0 + 1e-2 * rng.standard_normal((4096, nbod - 1, 3))
         e.vel[:, 1:, :] *= 1.0 + 1e-2 * rng.standard_normal((4096, nbod - 1, 3))
-        s = 0.1                                  # shrunk 10x: orbital periods of ~1 .. 3, so that 1e5 steps are many orbits
+        # s = 0.1: shrunk 10x, orbital periods of ~1 .. 3, so that 1e5 steps are many orbits; s = 1: the generated
+        # sizes (r = 10, 14: a twentieth of an orbit, the regime of trivial.py's BasicIntegration)
         e.pos *= s
         e.vel /= np.sqrt(s)
         h = S.HostEnsemble(4096, nbod)
         for k in ("pos", "vel", "mass", "time", "state", "id"):
             getattr(h, k)[...] = getattr(e, k)
         de = run(h, 10.0, 1e-4)
-        out["perturbed_4096x%d_dE_median_p90_max" % nbod] = [float(np.median(de)), float(np.quantile(de, 0.9)), float(de.max())]
+        tag = "perturbed_4096x%d%s" % (nbod, "" if s < 1 else "_unshrunk")
+        out[tag + "_dE_median_p90_max"] = [float(np.median(de)), float(np.quantile(de, 0.9)), float(de.max())]
         idx = np.arange(0, 4096, 64)
         o = O.generate(len(idx), nbod)
         for k in ("pos", "vel", "mass", "time", "state", "id"):
@@ -49,7 +57,7 @@ def main():
         O.integrate(o, O.params("hermite_cpu", 10.0, time_step=1e-4), threads=8)
         dp = np.sqrt(((h.pos[idx] - o.pos) ** 2).sum(-1)).max()
         dv = np.sqrt(((h.vel[idx] - o.vel) ** 2).sum(-1)).max()
-        out["perturbed_4096x%d_vs_hermite_cpu_pos_vel" % nbod] = [float(dp), float(dv)]
+        out[tag + "_vs_hermite_cpu_pos_vel"] = [float(dp), float(dv)]
     print(json.dumps(out))
 
 
