@@ -136,8 +136,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--nsys", type=int, default=65536, help="systems per GPU")
     ap.add_argument("--nbod", type=int, default=3)
     ap.add_argument("--time-step", type=float, default=1e-4)
