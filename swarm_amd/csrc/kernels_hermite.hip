@@ -147,44 +147,69 @@ __global__ __launch_bounds__(256) void hermite_kernel(EnsView e, IntParams ip, M
         // the loop -- MI355X issues FP64 VALU instructions at less than a third of the rate once 8 or fewer lanes of a
         // wavefront are enabled (tools/ubench_exec.hip), so a thinned-out wave would crawl through its tail.
         auto live = [&]() { return iter < ip.max_iterations && s.state == SWARM_HIP_ACTIVE; };
-        while (WHOLE ? __any(live()) : live()) {
-            const bool on = !WHOLE || live();
-            // A system that is done hands its state back at once: from here on its lane only keeps the wave whole, and
-            // whatever those h = 0 steps leave in its registers -- unchanged values as long as its forces are finite,
-            // NaN otherwise (0 * inf) -- is never written back.
-            if (WHOLE && !on && !stored) {
-                if (steps || s.state != state_in) store_state(e, gid, s);
-                stored = true;
-            }
-            double h;
-            if (ADAPTIVE) {
-                // calc_adaptive_time_step, hermite_adap.hpp:69-98: sum over bodies of |jerk|^2/|acc|^2
-                double tf = 0.0;
-#pragma unroll
-                for (int b = 0; b < N; b++) {
-                    // (explicit fused form: what the compiler's contraction gives, fixed so that the lane-per-body
-                    // kernel computes the same bits)
-                    const double a2 = __builtin_fma(fa[0][b][2], fa[0][b][2], __builtin_fma(fa[0][b][1], fa[0][b][1], fa[0][b][0] * fa[0][b][0]));
-                    const double jj = __builtin_fma(fj[0][b][2], fj[0][b][2], __builtin_fma(fj[0][b][1], fj[0][b][1], fj[0][b][0] * fj[0][b][0]));
-                    const double ra = rcp_full(a2); // jj / a2 through the reciprocal, fused into the running sum
-                    tf = (b == 0) ? jj * ra : __builtin_fma(jj, ra, tf);
+        constexpr bool PINGPONG = ADAPTIVE || WHOLE;
+        if constexpr (PINGPONG) {
+            // one step of the general loop: forces at the start of the step in (a0, j0), at its end in (a1, j1)
+            auto general_step = [&](const double (&a0)[N][3], const double (&j0)[N][3], double (&a1)[N][3], double (&j1)[N][3]) {
+                const bool on = !WHOLE || live();
+                // A system that is done hands its state back at once: from here on its lane only keeps the wave whole, and
+                // whatever those h = 0 steps leave in its registers -- unchanged values as long as its forces are finite,
+                // NaN otherwise (0 * inf) -- is never written back.
+                if (WHOLE && !on && !stored) {
+                    if (steps || s.state != state_in) store_state(e, gid, s);
+                    stored = true;
                 }
-                h = __builtin_fma(rsqrt_full(tf), ip.time_step_factor, ip.min_time_step);
-            } else {
-                h = ip.time_step;
-            }
-            {
+                double h;
+                if (ADAPTIVE) {
+                    // calc_adaptive_time_step, hermite_adap.hpp:69-98: sum over bodies of |jerk|^2/|acc|^2
+                    double tf = 0.0;
+#pragma unroll
+                    for (int b = 0; b < N; b++) {
+                        // (explicit fused form: what the compiler's contraction gives, fixed so that the lane-per-body
+                        // kernel computes the same bits)
+                        const double a2 = __builtin_fma(a0[b][2], a0[b][2], __builtin_fma(a0[b][1], a0[b][1], a0[b][0] * a0[b][0]));
+                        const double jj = __builtin_fma(j0[b][2], j0[b][2], __builtin_fma(j0[b][1], j0[b][1], j0[b][0] * j0[b][0]));
+                        const double ra = rcp_full(a2); // jj / a2 through the reciprocal, fused into the running sum
+                        tf = (b == 0) ? jj * ra : __builtin_fma(jj, ra, tf);
+                    }
+                    h = __builtin_fma(rsqrt_full(tf), ip.time_step_factor, ip.min_time_step);
+                } else {
+                    h = ip.time_step;
+                }
+                {
 #pragma clang fp contract(off)
-                if (s.t + h > dest) h = dest - s.t;
+                    if (s.t + h > dest) h = dest - s.t;
+                }
+                if (WHOLE && !on) h = 0.0;
+                if (ADAPTIVE || !WHOLE || h != k.h) k.template set<ADAPTIVE>(h);
+                finish_step(h, a0, j0, a1, j1, on);
+                if (on) iter++;
+            };
+            // two steps per trip through the ping-pong force buffers, as in the fast path: copying the 6 N doubles of
+            // (a1, j1) back into (a0, j0) after every step cost the adaptive kernel 3 % (nbod 3) to 18 % (nbod 10)
+            while (WHOLE ? __any(live()) : live()) {
+                general_step(fa[0], fj[0], fa[1], fj[1]);
+                if (!(WHOLE ? __any(live()) : live())) break;
+                general_step(fa[1], fj[1], fa[0], fj[0]);
             }
-            if (WHOLE && !on) h = 0.0;
-            if (ADAPTIVE || !WHOLE || h != k.h) k.template set<ADAPTIVE>(h);
-            finish_step(h, fa[0], fj[0], fa[1], fj[1], on);
-            if (on) iter++;
+        } else {
+            // The fixed-step kernel with nothing to monitor comes here for its clipped last step only; it keeps the
+            // plain loop with the copy (written out, not through the lambda above: with it the headline's fast loop,
+            // instruction for instruction the same, came out with another register assignment and 0.8 % slower).
+            while (live()) {
+                double h = ip.time_step;
+                {
+#pragma clang fp contract(off)
+                    if (s.t + h > dest) h = dest - s.t;
+                }
+                k.set(h);
+                finish_step(h, fa[0], fj[0], fa[1], fj[1], true);
+                iter++;
 #pragma unroll
-            for (int b = 0; b < N; b++)
+                for (int b = 0; b < N; b++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
+                    for (int c = 0; c < 3; c++) fa[0][b][c] = fa[1][b][c], fj[0][b][c] = fj[1][b][c];
+            }
         }
     }
     if (ghost) return;
