@@ -22,11 +22,12 @@ def split(raw):
     return sorted(out)
 
 
-def run(S, e, cfg, dest, buffers, cap):
+def run(S, e, cfg, dest, buffers, cap, stream=None):
     h = to_host(S, e)
     integ = S.Integrator.create(S.config(cfg))
     integ.set_ensemble(h)
     integ.set_destination_time(dest)
+    integ.stream = stream
     lm = S.LogManager(cap, "host", buffers=buffers)
     lm.replay_printf = False
     integ.set_log_manager(lm)
@@ -91,3 +92,26 @@ def test_overflow_is_counted_not_silent(gpu, oracle):
         h, raw, dropped, attempts, _ = run(S, e, dict(ADAP, **extra), 10.0, buffers, cap)
         got = len(split(raw))
         assert got + dropped == 21 * nsys and dropped > 0, (buffers, extra, got, dropped)
+
+
+def test_launches_on_a_stream_of_their_own(gpu, oracle):
+    """the launch stream need not be the NULL stream: kernels, the cursor copy and the clearing of a reused log's cursor
+    are ordered by the caller's stream, the copies by the manager's"""
+    import ctypes as C
+    S, O = gpu, oracle
+    nsys, nbod = 2000, 4
+    e = perturbed(O, nsys, nbod, seed=9)
+    cfg = dict(ADAP, max_iterations="6")
+    cap = 8 << 20
+    stream = C.c_void_p()
+    S.capi.check(S.capi.lib.swarm_hip_stream_create(C.byref(stream)))
+    try:
+        h1, raw1, d1, a1, _ = run(S, e, cfg, 20.0, 1, cap)
+        h2, raw2, d2, a2, _ = run(S, e, dict(cfg, log_batches="3"), 20.0, 2, cap, stream=stream)
+        h3, raw3, d3, a3, _ = run(S, e, cfg, 20.0, 1, cap, stream=stream)
+    finally:
+        S.capi.check(S.capi.lib.swarm_hip_stream_destroy(stream))
+    assert a1 == a2 == a3 > 5 and d1 == d2 == d3 == 0
+    assert split(raw1) == split(raw2) == split(raw3) and len(raw1) > 40 * 288 * nsys
+    for k in FIELDS:
+        assert (getattr(h1, k) == getattr(h2, k)).all() and (getattr(h1, k) == getattr(h3, k)).all(), k
