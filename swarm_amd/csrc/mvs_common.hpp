@@ -140,7 +140,10 @@ __device__ __forceinline__ void kepler_pass(KeplerOrbit &o, const KeplerConsts &
     const double ddF = __builtin_fma(o.sig0, b, o.foo * (xx * a));
     const double az = fabs(__builtin_fma(16.0 * dF, dF, -20.0 * (F * ddF)));
     const double z = az * rsqrt_full(fmax(az, 1e-300)); // sqrt; 0 for az = 0
-    double denom = dF < 0 ? dF - z : dF + z;
+    // dF + SIGN(dF) z, keplerian.hpp:150-151, as one sign transfer and one addition: `dF < 0 ? dF - z : dF + z` differs
+    // from dF + copysign(z, dF) only for dF = -0.0, which the sum above cannot produce (a cancellation to zero gives
+    // +0.0 in round-to-nearest, and its addend r0 is positive), and both give NaN for a NaN
+    double denom = dF + __builtin_copysign(z, dF);
     if (denom == 0.0) denom = 1e-8;
     const double f5 = 5.0 * F, rd = rcp_full(denom);
     const double un = f5 * rd; // the correction, kept for the convergence test; x - un in one rounding, off un's chain
@@ -156,8 +159,9 @@ __device__ __forceinline__ void kepler_end(const KeplerOrbit &o, const KeplerCon
     const double x_p = o.x, x2 = x_p * x_p;
     const double a = __builtin_fma(-y, S, 1.0);
     const double x2C = x2 * C;
-    double r = __builtin_fma(o.sig0 * x_p, a, __builtin_fma(o.foo, x2C, o.r0));
-    if (r < 0.) r = 0.;
+    // `if (r < 0) r = 0`, keplerian.hpp:210-211, as one maximum (a NaN, which the comparison keeps and the maximum
+    // turns into 0, ends as NaN in the reciprocal below either way; -0.0 cannot come out of a sum with r0 > 0)
+    const double r = fmax(__builtin_fma(o.sig0 * x_p, a, __builtin_fma(o.foo, x2C, o.r0)), 0.);
     const double g_p = __builtin_fma(-(x2 * x_p) * k.inv_smu, S, k.dt);
     // fh = f - 1 and gh = dg/dt - 1 (keplerian.hpp:214, 218)
     const double fh = -(x2C * o.inv_r0);
