@@ -28,10 +28,10 @@ extern "C" {
 
 #define SWARM_HIP_CHUNK 64
 #define SWARM_HIP_MIN_NBOD 3
-/* nbod 3 .. 10 run one lane per system or one lane per body (swarm_hip_launch_t::lane_mode); 11 .. 16 one lane per
- * body only.  The reference instantiates 3 .. MAX_NBODIES (cmake/variables.cmake:55-72, default 6) and ships golden
- * outputs up to nbod 13 (test/integrators/test.13.out.txt). */
-#define SWARM_HIP_MAX_NBOD 16
+/* nbod 3 .. 10 run one lane per system or one lane per body (swarm_hip_launch_t::lane_mode); 11 .. 32 one lane per
+ * body only.  The reference instantiates 3 .. MAX_NBODIES, accepts MAX_NBODIES up to 32 (cmake/variables.cmake:55-72,
+ * default 6) and ships golden outputs up to nbod 13 (test/integrators/test.13.out.txt). */
+#define SWARM_HIP_MAX_NBOD 32
 #define SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM 10
 
 /* error codes */

@@ -19,6 +19,7 @@ INTEGRATORS = {
     "mvs": 5, "euler": 6, "verlet": 7, "midpoint": 8, "hermite_prop": 9, "irk2_cpu": 10, "irk2": 11,
 }
 FLT_MAX = float(np.finfo(np.float32).max)
+MAX_NBOD = 32  # ORC_MAX_NBOD, swarm_oracle.h
 
 
 def build(force=False):

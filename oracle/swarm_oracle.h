@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_NBOD 16
+#define ORC_MAX_NBOD 32
 
 /* reference: src/swarm/types/ensemble.hpp:269-274 */
 enum { ORC_ACTIVE = 0, ORC_INACTIVE = 1, ORC_NEEDS_EXAM = 2, ORC_DISABLED = -1 };

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SWARM_HIP_LIB") or os.path.join(_HERE, "lib", "libswa
 
 CHUNK = 64
 NOALLOC_MAX_NSYS = 1 << 26
-MIN_NBOD, MAX_NBOD, MAX_NBOD_LANE_PER_SYSTEM = 3, 16, 10
+MIN_NBOD, MAX_NBOD, MAX_NBOD_LANE_PER_SYSTEM = 3, 32, 10
 ACTIVE, INACTIVE, NEEDS_EXAM, DISABLED = 0, 1, 2, -1
 HERMITE, HERMITE_ADAP, RKCK_FIXED, RKCK_ADAPTIVE, MVS, EULER, VERLET, MIDPOINT, HERMITE_PROP, IRK2, IRK2_CPU = range(1, 12)
 MON_EJECTION, MON_LOG_INTERVAL, MON_EJECTION_OR_CLOSE, MON_MCE_STAT, MON_LOG_TRANSIT = 0, 1, 2, 3, 4

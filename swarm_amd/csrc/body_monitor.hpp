@@ -61,7 +61,7 @@ struct BodyMonitor {
             const bool ce_part = take_part && !want;
             bool ce = false;
             if (mp.ce_any) {
-#pragma unroll
+                SWH_BODY_LOOP
                 for (int d = 1; d < N - 1; d++) {
                     const double pj[3] = {__shfl(p[0], star + d), __shfl(p[1], star + d), __shfl(p[2], star + d)};
                     double sep;

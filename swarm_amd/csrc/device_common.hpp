@@ -300,6 +300,22 @@ struct LaneExchange {
     static __device__ __forceinline__ void done() { __syncthreads(); } // loads before the next put()
 };
 
+// Lane-per-body kernels beyond nbod = BODY_UNROLL_MAX (17 .. 32: three or two systems per wavefront): the loops over a
+// body's partners stay ROLLED, eight partners per trip, and the partners' masses are read from a row in LDS instead of
+// nbod - 1 registers.  Unrolled in full, the nbod-32 kernels take 256 VGPRs + 256 AGPRs + 1.0 ... 1.4 KB of scratch
+// per lane, and the sixteen extra instantiations of every kernel four times the library's size and build time.
+// Up to BODY_UNROLL_MAX nothing changes: the same instructions as before.  SWH_BODY_LOOP goes before such a loop in
+// a kernel templated on N.
+constexpr int BODY_UNROLL_MAX = 16;
+template <int N>
+struct BodyLoops {
+    static constexpr bool ROLLED = N > BODY_UNROLL_MAX;
+    static constexpr int UNROLL = ROLLED ? 8 : N;
+    static constexpr int UNROLL_OUTER = ROLLED ? 1 : N;
+};
+#define SWH_BODY_LOOP _Pragma("unroll BodyLoops<N>::UNROLL")
+#define SWH_BODY_LOOP_OUTER _Pragma("unroll BodyLoops<N>::UNROLL_OUTER") /* around a SWH_BODY_LOOP: one trip at a time */
+
 // ---------------------------------------------------------------------------------------------
 // Per-step constants that depend only on h.  For the fixed-step integrator h changes at most once
 // per launch (the clipped last step), so they are recomputed only when h changes.

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     constexpr int G = W / N; // systems per wavefront
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM;
+    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     // own body, the partners' masses, the system's time and state (every lane of a group holds a copy)
     const size_t chunk = sys / W, sl = sys % W;
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
-    double p[3], v[3], mo[N - 1], t = 0.0;
-    const double m_own = (EJ && valid) ? row[6 * W] : 1.0;
+    double p[3], v[3], mo[ROLLED ? 1 : N - 1], t = 0.0;
+    const double m_own = ((EJ || ROLLED) && valid) ? row[6 * W] : 1.0;
     const int id = (EJ && valid) ? e.sysi[(sys / W) * 2 * W + W + sys % W] : 0;
     const unsigned long long group_mask = ((1ull << N) - 1) << base; // lanes of my system (base + N <= 64 when valid)
     int state = SWARM_HIP_DISABLED;
@@ -46,11 +47,24 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
         p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
         v[c] = valid ? row[(3 + c) * W] : 0.0;
     }
+    __shared__ double mass_row[W]; // ROLLED only: the mass of every lane's body
+    if constexpr (ROLLED) {
+        mass_row[lane] = m_own;
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int q = 0; q < N - 1; q++) {
-        const int j = q < b ? q : q + 1; // partners in increasing index order
-        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        for (int q = 0; q < N - 1; q++) {
+            const int j = q < b ? q : q + 1; // partners in increasing index order
+            mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        }
     }
+    // mass of my q-th partner, who sits in lane `src`
+    auto partner_mass = [&](const int q, const int src) {
+        if constexpr (ROLLED)
+            return mass_row[src];
+        else
+            return mo[q];
+    };
     if (valid) {
         t = e.sysd[chunk * e.nsf * W + sl];
         state = e.sysi[chunk * 2 * W + sl];
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, state, mp, lg,
                 [](bool, bool) {});
     };
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
@@ -75,10 +89,12 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             const double pv6[6] = {p[0], p[1], p[2], v[0], v[1], v[2]};
             Xchg::put(xchg, lane, pv6);
         }
-#pragma unroll
+        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = 0.0;
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double o[6];
-            Xchg::get(xchg, (base + (q < b ? q : q + 1)) & (W - 1), o);
+            const int src = (base + (q < b ? q : q + 1)) & (W - 1);
+            Xchg::get(xchg, src, o);
             const double d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
             const double e0 = o[3] - v[0], e1 = o[4] - v[1], e2 = o[5] - v[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
@@ -87,9 +103,9 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             const double y2 = y * y;
             const double rinv = y * y2;
             const double rv = (xv * 3.0) * y2;
-            const double sc = rinv * mo[q];
+            const double sc = rinv * partner_mass(q, src);
             const double t0 = __builtin_fma(-d0, rv, e0), t1 = __builtin_fma(-d1, rv, e1), t2 = __builtin_fma(-d2, rv, e2);
-            if (q == 0) {
+            if (!ROLLED && q == 0) {
                 a[0] = d0 * sc, a[1] = d1 * sc, a[2] = d2 * sc;
                 jk[0] = t0 * sc, jk[1] = t1 * sc, jk[2] = t2 * sc;
             } else {
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             const double jj = __builtin_fma(j0[2], j0[2], __builtin_fma(j0[1], j0[1], j0[0] * j0[0]));
             const double ra = rcp_full(a2);
             double tf = __shfl(jj, base) * __shfl(ra, base);
-#pragma unroll
+            SWH_BODY_LOOP
             for (int j = 1; j < N; j++) tf = __builtin_fma(__shfl(jj, base + j), __shfl(ra, base + j), tf);
             h = __builtin_fma(rsqrt_full(tf), ip.time_step_factor, ip.min_time_step);
         }

@@ -26,6 +26,7 @@ template <int N, int MONB>
 __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
+    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: loops over the bodies rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -35,31 +36,47 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 
     const size_t chunk = sys / W, sl = sys % W;
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
-    double p[3], v[3], m[N], t = 0.0;
+    double p[3], v[3], m[ROLLED ? 1 : N], t = 0.0;
     int state = SWARM_HIP_DISABLED;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         p[c] = valid ? row[c * W] : (c == 0 ? 1.0 + lane : 0.0); // idle lanes: distinct finite dummies
         v[c] = valid ? row[(3 + c) * W] : 0.0;
     }
+    __shared__ double mass_row[W]; // ROLLED only: the mass of every lane's body
+    double m_own;
+    if constexpr (ROLLED) {
+        m_own = valid ? row[6 * W] : 1.0;
+        mass_row[lane] = m_own;
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int j = 0; j < N; j++) m[j] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        for (int j = 0; j < N; j++) m[j] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+    }
+    // mass of body j of my system
+    auto mass_of = [&](const int j) {
+        if constexpr (ROLLED)
+            return mass_row[base + j];
+        else
+            return m[j];
+    };
     if (valid) {
         t = e.sysd[chunk * e.nsf * W + sl];
         state = e.sysi[chunk * 2 * W + sl];
     }
     const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
-    double m_own = m[0];
+    double mo[(!ROLLED && N - 2 > 0) ? N - 2 : 1]; // the fellow planets' masses, in increasing index order
+    if constexpr (!ROLLED) {
+        m_own = m[0];
 #pragma unroll
-    for (int j = 1; j < N; j++) m_own = b == j ? m[j] : m_own;
-
-    double mo[N - 2 > 0 ? N - 2 : 1]; // the fellow planets' masses, in increasing index order
+        for (int j = 1; j < N; j++) m_own = b == j ? m[j] : m_own;
 #pragma unroll
-    for (int q = 0; q < N - 2; q++) {
-        const int k = (q + 1 < b) ? q + 1 : q + 2;
-        mo[q] = m[1];
+        for (int q = 0; q < N - 2; q++) {
+            const int k = (q + 1 < b) ? q + 1 : q + 2;
+            mo[q] = m[1];
 #pragma unroll
-        for (int j = 2; j < N; j++) mo[q] = k == j ? m[j] : mo[q];
+            for (int j = 2; j < N; j++) mo[q] = k == j ? m[j] : mo[q];
+        }
     }
 
     const bool mine = valid && state == SWARM_HIP_ACTIVE; // only these systems are converted, integrated and stored
@@ -74,11 +91,12 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
         for (int c = 0; c < 3; c++) {
             const double pc0 = __shfl(p[c], base);
             double sump = 0., sumv = 0., mtot = 0.;
-#pragma unroll
+            SWH_BODY_LOOP
             for (int j = 0; j < N; ++j) {
-                mtot += m[j];
-                sump = __builtin_fma(m[j], __shfl(p[c], base + j), sump);
-                sumv = __builtin_fma(m[j], __shfl(v[c], base + j), sumv);
+                const double mj = mass_of(j);
+                mtot += mj;
+                sump = __builtin_fma(mj, __shfl(p[c], base + j), sump);
+                sumv = __builtin_fma(mj, __shfl(v[c], base + j), sumv);
             }
             sumv /= mtot;
             const double cp = sump / mtot;
@@ -92,13 +110,14 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             double sump = 0., sumv = 0.;
-            const double m0 = m[0], pc0 = __shfl(p[c], base), vc0 = __shfl(v[c], base);
+            const double m0 = mass_of(0), pc0 = __shfl(p[c], base), vc0 = __shfl(v[c], base);
             double mtot = m0;
-#pragma unroll
+            SWH_BODY_LOOP
             for (int j = 1; j < N; ++j) {
-                mtot += m[j];
-                sump = __builtin_fma(m[j], __shfl(p[c], base + j), sump);
-                sumv = __builtin_fma(m[j], __shfl(v[c], base + j), sumv);
+                const double mj = mass_of(j);
+                mtot += mj;
+                sump = __builtin_fma(mj, __shfl(p[c], base + j), sump);
+                sumv = __builtin_fma(mj, __shfl(v[c], base + j), sumv);
             }
             sump /= mtot;
             const double dv0 = sumv / m0, dp = pc0 - sump;
@@ -118,12 +137,13 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 #pragma clang fp contract(off)
         Xchg::put(xchg, lane, v);
         mv[0] = mv[1] = mv[2] = 0.0;
-#pragma unroll
+        SWH_BODY_LOOP
         for (int j = 1; j < N; ++j) {
             double vj[3];
             Xchg::get(xchg, base + j, vj);
+            const double mj = mass_of(j);
 #pragma unroll
-            for (int c = 0; c < 3; c++) mv[c] = __builtin_fma(m[j], vj[c], mv[c]);
+            for (int c = 0; c < 3; c++) mv[c] = __builtin_fma(mj, vj[c], mv[c]);
         }
         Xchg::done();
     };
@@ -140,15 +160,21 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     auto planet_forces = [&](double (&a)[3]) {
         Xchg::put(xchg, lane, p);
         a[0] = a[1] = a[2] = 0.0;
-#pragma unroll
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 2; q++) {
             double pj[3];
-            Xchg::get(xchg, base + ((q + 1 < b) ? q + 1 : q + 2), pj); // fellow planets in increasing index order
+            const int k = (q + 1 < b) ? q + 1 : q + 2; // fellow planets in increasing index order
+            Xchg::get(xchg, base + k, pj);
             const double d0 = pj[0] - p[0], d1 = pj[1] - p[1], d2 = pj[2] - p[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double y = rsqrt_full(r2);
             const double rinv = y * (y * y);
-            const double sc = rinv * mo[q];
+            double mk;
+            if constexpr (ROLLED)
+                mk = mass_of(k);
+            else
+                mk = mo[q];
+            const double sc = rinv * mk;
             a[0] = __builtin_fma(d0, sc, a[0]);
             a[1] = __builtin_fma(d1, sc, a[1]);
             a[2] = __builtin_fma(d2, sc, a[2]);
@@ -192,7 +218,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return m[d]; }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, state, mp, lg,
                 [&](const bool who, const bool std_coordinates) {
                     if (std_coordinates)
                         to_std(who);
@@ -203,9 +229,9 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
 
     if (__any(mine)) {
         const double dest = ip.destination_time;
-        const double inv_m0 = 1.0 / m[0];
+        const double inv_m0 = 1.0 / mass_of(0);
         KeplerConsts kc;
-        kc.set_star(sqrt(m[0]));
+        kc.set_star(sqrt(mass_of(0)));
         double acc[3];
         // prop.init()
         to_internal(mine);

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF;
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
+    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
 
     const size_t chunk = sys / W, sl = sys % W;
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
-    double p[3], v[3], mo[N - 1], t = 0.0;
+    double p[3], v[3], mo[ROLLED ? 1 : N - 1], t = 0.0;
     int state = SWARM_HIP_DISABLED;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -41,11 +42,24 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     }
     const double m_own = valid ? row[6 * W] : 1.0;
     const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
+    __shared__ double mass_row[W]; // ROLLED only: the mass of every lane's body
+    if constexpr (ROLLED) {
+        mass_row[lane] = m_own;
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int q = 0; q < N - 1; q++) {
-        const int j = q < b ? q : q + 1; // partners in increasing index order
-        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        for (int q = 0; q < N - 1; q++) {
+            const int j = q < b ? q : q + 1; // partners in increasing index order
+            mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        }
     }
+    // mass of my q-th partner, who sits in lane `src`
+    auto partner_mass = [&](const int q, const int src) {
+        if constexpr (ROLLED)
+            return mass_row[src];
+        else
+            return mo[q];
+    };
     if (valid) {
         t = e.sysd[chunk * e.nsf * W + sl];
         state = e.sysi[chunk * 2 * W + sl];
@@ -61,10 +75,12 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             const double pv6[6] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2]};
             Xchg6::put(xchg6, lane, pv6);
         }
-#pragma unroll
+        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = 0.0;
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double o[6];
-            Xchg6::get(xchg6, base + (q < b ? q : q + 1), o);
+            const int src = base + (q < b ? q : q + 1);
+            Xchg6::get(xchg6, src, o);
             const double d0 = o[0] - pos[0], d1 = o[1] - pos[1], d2 = o[2] - pos[2];
             const double e0 = o[3] - vel[0], e1 = o[4] - vel[1], e2 = o[5] - vel[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
@@ -73,9 +89,9 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             const double y2 = y * y;
             const double rinv = y * y2;
             const double rv = (xv * 3.0) * y2;
-            const double sc = rinv * mo[q];
+            const double sc = rinv * partner_mass(q, src);
             const double t0 = __builtin_fma(-d0, rv, e0), t1 = __builtin_fma(-d1, rv, e1), t2 = __builtin_fma(-d2, rv, e2);
-            if (q == 0) {
+            if (!ROLLED && q == 0) {
                 a[0] = d0 * sc, a[1] = d1 * sc, a[2] = d2 * sc;
                 jk[0] = t0 * sc, jk[1] = t1 * sc, jk[2] = t2 * sc;
             } else {
@@ -90,15 +106,16 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     auto acc_body = [&](const double (&pos)[3], double (&a)[3]) {
         Xchg3::put(xchg3, lane, pos);
         a[0] = a[1] = a[2] = 0.0;
-#pragma unroll
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double pj[3];
-            Xchg3::get(xchg3, base + (q < b ? q : q + 1), pj);
+            const int src = base + (q < b ? q : q + 1);
+            Xchg3::get(xchg3, src, pj);
             const double d0 = pj[0] - pos[0], d1 = pj[1] - pos[1], d2 = pj[2] - pos[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double y = rsqrt_full(r2);
             const double rinv = y * (y * y);
-            const double sc = rinv * mo[q];
+            const double sc = rinv * partner_mass(q, src);
             a[0] = __builtin_fma(d0, sc, a[0]);
             a[1] = __builtin_fma(d1, sc, a[1]);
             a[2] = __builtin_fma(d2, sc, a[2]);
@@ -109,22 +126,23 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     __shared__ double pair_terms[KIND == SWARM_HIP_VERLET ? N - 1 : 1][W];
     auto verlet_timestep_body = [&](const double (&pos)[3]) -> double {
         Xchg3::put(xchg3, lane, pos);
-#pragma unroll
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double pj[3];
-            Xchg3::get(xchg3, base + (q < b ? q : q + 1), pj);
+            const int src = base + (q < b ? q : q + 1);
+            Xchg3::get(xchg3, src, pj);
             // slot q is partner j = q (j < b) or q + 1; the star's lane has planets in every slot, a planet's slot 0
             // is the star, which is no term
             pair_terms[KIND == SWARM_HIP_VERLET ? q : 0][lane] =
-                verlet_pair_term(pj[0] - pos[0], pj[1] - pos[1], pj[2] - pos[2], m_own + mo[q]);
+                verlet_pair_term(pj[0] - pos[0], pj[1] - pos[1], pj[2] - pos[2], m_own + partner_mass(q, src));
         }
         __syncthreads(); // a single wavefront: the terms are stored before they are read
         double sum = 0.0;
         {
 #pragma clang fp contract(off)
-#pragma unroll
+            SWH_BODY_LOOP_OUTER
             for (int i = 0; i < N; i++)
-#pragma unroll
+                SWH_BODY_LOOP
                 for (int j = 1; j < N; j++) {
                     if (i == j) continue;
                     sum = sum + pair_terms[KIND == SWARM_HIP_VERLET ? (j < i ? j : j - 1) : 0][base + i];
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto call_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, state, mp, lg,
                 [](bool, bool) {});
     };
 

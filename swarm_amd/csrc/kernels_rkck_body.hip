@@ -24,6 +24,7 @@ template <int N, bool ADAPTIVE, int MONB>
 __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
+    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
 
     const size_t chunk = sys / W, sl = sys % W;
     double *row = e.body + ((chunk * N + b) * e.nbf) * W + sl;
-    double p[3], v[3], mo[N - 1], t = 0.0;
+    double p[3], v[3], mo[ROLLED ? 1 : N - 1], t = 0.0;
     int state = SWARM_HIP_DISABLED;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -42,11 +43,24 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     }
     const double m_own = valid ? row[6 * W] : 1.0;
     const int id = (EJ && valid) ? e.sysi[chunk * 2 * W + W + sl] : 0;
+    __shared__ double mass_row[W]; // ROLLED only: the mass of every lane's body
+    if constexpr (ROLLED) {
+        mass_row[lane] = m_own;
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int q = 0; q < N - 1; q++) {
-        const int j = q < b ? q : q + 1; // partners in increasing index order
-        mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        for (int q = 0; q < N - 1; q++) {
+            const int j = q < b ? q : q + 1; // partners in increasing index order
+            mo[q] = valid ? e.body[((chunk * N + j) * e.nbf + 6) * W + sl] : 1.0;
+        }
     }
+    // mass of my q-th partner, who sits in lane `src`
+    auto partner_mass = [&](const int q, const int src) {
+        if constexpr (ROLLED)
+            return mass_row[src];
+        else
+            return mo[q];
+    };
     if (valid) {
         t = e.sysd[chunk * e.nsf * W + sl];
         state = e.sysi[chunk * 2 * W + sl];
@@ -60,15 +74,16 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     auto force = [&](const double (&pos)[3], double (&a)[3]) {
         Xchg::put(xchg, lane, pos);
         a[0] = a[1] = a[2] = 0.0;
-#pragma unroll
+        SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double pj[3];
-            Xchg::get(xchg, base + (q < b ? q : q + 1), pj);
+            const int src = base + (q < b ? q : q + 1);
+            Xchg::get(xchg, src, pj);
             const double d0 = pj[0] - pos[0], d1 = pj[1] - pos[1], d2 = pj[2] - pos[2];
             const double r2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
             const double y = rsqrt_full(r2);
             const double rinv = y * (y * y);
-            const double sc = rinv * mo[q];
+            const double sc = rinv * partner_mass(q, src);
             a[0] = __builtin_fma(d0, sc, a[0]);
             a[1] = __builtin_fma(d1, sc, a[1]);
             a[2] = __builtin_fma(d2, sc, a[2]);
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mo[d]; }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, state, mp, lg,
                 [](bool, bool) {});
     };
     if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
         if (ADAPTIVE) {
             const double mine = rkck_body_error(pe, ve, p6, v6);
             double max_error = 0;
-#pragma unroll
+            SWH_BODY_LOOP
             for (int j = 0; j < N; j++) max_error = fmax(__shfl(mine, base + j), max_error);
             accept_step = rkck_step_control(max_error, time_step, ip); // L204-269, the same in every lane of the system
         }

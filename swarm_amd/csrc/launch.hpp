@@ -94,6 +94,22 @@ int launch_irk2_body(const LaunchCtx &c, int method, bool cpu_rules); // one lan
     case 14: { constexpr int N = 14; CALL; } break;                        \
     case 15: { constexpr int N = 15; CALL; } break;                        \
     case 16: { constexpr int N = 16; CALL; } break;                        \
+    case 17: { constexpr int N = 17; CALL; } break;                        \
+    case 18: { constexpr int N = 18; CALL; } break;                        \
+    case 19: { constexpr int N = 19; CALL; } break;                        \
+    case 20: { constexpr int N = 20; CALL; } break;                        \
+    case 21: { constexpr int N = 21; CALL; } break;                        \
+    case 22: { constexpr int N = 22; CALL; } break;                        \
+    case 23: { constexpr int N = 23; CALL; } break;                        \
+    case 24: { constexpr int N = 24; CALL; } break;                        \
+    case 25: { constexpr int N = 25; CALL; } break;                        \
+    case 26: { constexpr int N = 26; CALL; } break;                        \
+    case 27: { constexpr int N = 27; CALL; } break;                        \
+    case 28: { constexpr int N = 28; CALL; } break;                        \
+    case 29: { constexpr int N = 29; CALL; } break;                        \
+    case 30: { constexpr int N = 30; CALL; } break;                        \
+    case 31: { constexpr int N = 31; CALL; } break;                        \
+    case 32: { constexpr int N = 32; CALL; } break;                        \
     default:                                                               \
         set_error("nbod=%d outside [%d,%d]", nbod, SWARM_HIP_MIN_NBOD, SWARM_HIP_MAX_NBOD); \
         return SWARM_HIP_EINVAL;                                           \

@@ -1,6 +1,9 @@
-"""nbod 11 .. 16: one lane per body only (SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM = 10 < nbod <= SWARM_HIP_MAX_NBOD).
-The reference instantiates nbod = 3 .. MAX_NBODIES (cmake/variables.cmake:55-72), its ctest loops over that range
-(cmake/test_integrators.cmake:33-39) and it ships golden pairs up to test.13.{in,out}.txt.  Bars: the goldens at the
+"""nbod 11 .. 32: one lane per body only (SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM = 10 < nbod <= SWARM_HIP_MAX_NBOD = 32).
+The reference instantiates nbod = 3 .. MAX_NBODIES and accepts MAX_NBODIES up to 32 (cmake/variables.cmake:55-72), its
+ctest loops over that range (cmake/test_integrators.cmake:33-39) and it ships golden pairs up to test.13.{in,out}.txt;
+beyond 13 the oracle is the only check.  From nbod 17 on the kernels' loops over a body's partners are rolled and the
+masses sit in LDS (BodyLoops, device_common.hpp): 17, 21, 22 and 32 are the ends of the three- and two-systems-per-
+wavefront ranges.  Bars: the goldens at the
 ctest's 1e-8, the oracle at north_star's 1e-10 with bit-exact times, states and step counts of fixed-step integrators."""
 import os
 
@@ -35,9 +38,9 @@ def test_hermite_vs_reference_golden_files_nbod_11_13(gpu, oracle, nbod):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("nbod", [11, 13, 16])
-def test_integrator_vs_oracle_nbod_11_16(gpu, oracle, name, nbod):
-    """every integrator on a ragged ensemble (37 systems: 5 or 4 per wavefront, a last wavefront of 2 or 1)"""
+@pytest.mark.parametrize("nbod", [11, 13, 16, 17, 21, 22, 32])
+def test_integrator_vs_oracle_nbod_11_32(gpu, oracle, name, nbod):
+    """every integrator on a ragged ensemble (37 systems: 5, 4, 3 or 2 per wavefront, a last wavefront of 2 or 1)"""
     S, O = gpu, oracle
     cfg, okw, T = CASES[name]
     T = 0.5
@@ -60,7 +63,7 @@ def test_integrator_vs_oracle_nbod_11_16(gpu, oracle, name, nbod):
         np.testing.assert_allclose(h.time, e.time, rtol=1e-12)
 
 
-@pytest.mark.parametrize("nbod", [12, 16])
+@pytest.mark.parametrize("nbod", [12, 16, 19, 32])
 def test_monitors_nbod_above_10(gpu, oracle, nbod):
     """stop_on_ejection (deactivate + log) and log_time_interval beyond nbod 10: stop flags, stop times and the
     records' bytes against the oracle"""
@@ -125,6 +128,6 @@ def test_what_stops_at_nbod_10_says_so(gpu, oracle):
             continue
         with pytest.raises(S.capi.SwarmHipError, match="one lane per body"):
             integ.integrate()
-    h17 = S.HostEnsemble(4, 17)
+    h33 = S.HostEnsemble(4, 33)
     with pytest.raises(S.capi.SwarmHipError, match="nbod"):
-        S.DeviceEnsemble(4, 17).upload(h17)
+        S.DeviceEnsemble(4, 33).upload(h33)

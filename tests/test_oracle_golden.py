@@ -121,11 +121,30 @@ def test_pair_map_covers_all_pairs(oracle):
     """src/utils/unit_tests.cpp:39-75: first/second<nbod>(ij) enumerates every unordered pair once"""
     O = oracle
     assert [O.pair(3, ij) for ij in range(3)] == [(2, 0), (1, 0), (2, 1)]
-    for nbod in range(3, 10):
+    for nbod in range(3, O.MAX_NBOD + 1):
         P = nbod * (nbod - 1) // 2
         pairs = {O.pair(nbod, ij) for ij in range(P)}
         assert len(pairs) == P
         assert all(0 <= b < a < nbod for a, b in pairs)
+
+
+@pytest.mark.parametrize("nbod", [14, 17, 24, 32])
+def test_restatements_beyond_the_golden_range(oracle, nbod):
+    """nbod 14 .. 32 (cmake/variables.cmake:55-72 accepts MAX_NBODIES up to 32; the goldens stop at 13): hermite_cpu
+    on generated systems conserves energy as it does below 13, and the GPU-form restatements agree with it to the bar
+    they meet against the goldens"""
+    O = oracle
+    assert O.MAX_NBOD == 32
+    g = O.generate(4, nbod)
+    e0 = O.total_energy(g)
+    ref = g.clone()
+    O.integrate(ref, O.params("hermite_cpu", 1.0, time_step=0.01))
+    assert np.abs((O.total_energy(ref) - e0) / e0).max() < 1e-9
+    for name, kw in (("hermite", {"time_step": 0.01}), ("hermite_prop", {"time_step": 0.01})):
+        e = g.clone()
+        O.integrate(e, O.params(name, 1.0, **kw))
+        pd, vd, td = O.compare(e, ref)
+        assert pd < 1e-10 and vd < 1e-10 and td < 1e-12, (name, pd, vd, td)
 
 
 def test_snapshot_record_layout(oracle):
