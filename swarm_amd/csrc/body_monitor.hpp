@@ -27,7 +27,7 @@ inline int body_monitor_of(const MonParams &mp) {
     }
 }
 
-template <int N, int MONB>
+template <int N, int MONB, bool ROLLED = BodyLoops<N>::ROLLED>
 struct BodyMonitor {
     double next_log_time; // log_time_interval.hpp:118-119
     bool ce_met;          // stop_on_close_encounter's condition_met, kept between calls as the monitor object does
@@ -50,6 +50,7 @@ struct BodyMonitor {
                                                const int id, int &state, const MonParams &mp, const LogBuf &lg,
                                                Convert &&convert) {
         if (MONB == MONB_OFF) return;
+        [[maybe_unused]] constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED);
         bool want = false, ej_met = false;
         if (MONB == MONB_EJECTION || MONB == MONB_EJECTION_OR_CLOSE) { // pass_one, stop_on_ejection.hpp:177-193
             const bool ej = take_part && b >= 1 && mp.ej_any && ej_test_quiet(p, v, m_own, mp);

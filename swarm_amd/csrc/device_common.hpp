@@ -300,21 +300,27 @@ struct LaneExchange {
     static __device__ __forceinline__ void done() { __syncthreads(); } // loads before the next put()
 };
 
-// Lane-per-body kernels beyond nbod = BODY_UNROLL_MAX (17 .. 32: three or two systems per wavefront): the loops over a
-// body's partners stay ROLLED, eight partners per trip, and the partners' masses are read from a row in LDS instead of
-// nbod - 1 registers.  Unrolled in full, the nbod-32 kernels take 256 VGPRs + 256 AGPRs + 1.0 ... 1.4 KB of scratch
-// per lane, and the sixteen extra instantiations of every kernel four times the library's size and build time.
-// Up to BODY_UNROLL_MAX nothing changes: the same instructions as before.  SWH_BODY_LOOP goes before such a loop in
-// a kernel templated on N.
+// Lane-per-body kernels, the two forms of the loops over a body's partners.  UNROLLED in full, the partners' masses in
+// nbod - 1 registers: every LDS load of an exchange is in flight at once, which is what a lone wavefront on its SIMD
+// needs, at the price of registers (nbod 13: 256 VGPRs + 29 ... 98 AGPRs, one wavefront per SIMD whatever the ensemble
+// size; nbod 32: 256 + 256 + 1.0 ... 1.4 KB of scratch per lane, and sixteen such instantiations of every kernel would
+// take the library from 35 to 150 MB).  ROLLED, eight partners per trip, the masses read from a row in LDS: half the
+// registers, so several wavefronts share a SIMD and hide one another's LDS latency.  Up to BODY_UNROLL_MAX the kernels
+// are unrolled (instruction for instruction what they were before the rolled form existed), beyond it (17 .. 32) rolled;
+// the Hermite kernels are built in BOTH forms for nbod 12 .. 16 and MVS for 14 .. 16, where the rolled form is 10 - 30 % ahead
+// once there is more than about a wavefront and a half per SIMD (profiles/r3/body_rolled_sweep_nbod_11_16.txt) and
+// the launcher picks by the number of ACTIVE systems; rkck, irk2 and verlet lose with it at every size and are not.
+// Both forms perform the same operations in the same order: bit-identical results (tests/test_gpu_nbod_11_32.py).
+// SWH_BODY_LOOP goes before such a loop; it expects `BODY_TRIP` (= BodyLoops<N>::trip(ROLLED)) in scope.
 constexpr int BODY_UNROLL_MAX = 16;
 template <int N>
 struct BodyLoops {
-    static constexpr bool ROLLED = N > BODY_UNROLL_MAX;
-    static constexpr int UNROLL = ROLLED ? 8 : N;
-    static constexpr int UNROLL_OUTER = ROLLED ? 1 : N;
+    static constexpr bool ROLLED = N > BODY_UNROLL_MAX; // the form of a kernel that is built in one form only
+    static constexpr int trip(const bool rolled) { return rolled ? 8 : N; }
+    static constexpr int outer_trip(const bool rolled) { return rolled ? 1 : N; } // around a SWH_BODY_LOOP
 };
-#define SWH_BODY_LOOP _Pragma("unroll BodyLoops<N>::UNROLL")
-#define SWH_BODY_LOOP_OUTER _Pragma("unroll BodyLoops<N>::UNROLL_OUTER") /* around a SWH_BODY_LOOP: one trip at a time */
+#define SWH_BODY_LOOP _Pragma("unroll BODY_TRIP")
+#define SWH_BODY_LOOP_OUTER _Pragma("unroll BODY_TRIP_OUTER")
 
 // ---------------------------------------------------------------------------------------------
 // Per-step constants that depend only on h.  For the fixed-step integrator h changes at most once

@@ -22,12 +22,12 @@
 
 namespace swh {
 
-template <int N, int MONB, bool ADAPTIVE>
+template <int N, int MONB, bool ADAPTIVE, bool ROLLED>
 __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     constexpr int G = W / N; // systems per wavefront
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM;
-    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
+    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED); // ROLLED: partner loops rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     }
     const int state_in = state;
     // The monitor of one system, called by the whole wavefront (body_monitor.hpp)
-    BodyMonitor<N, MONB> monitor;
+    BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
         monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, state, mp, lg,
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
             const double pv6[6] = {p[0], p[1], p[2], v[0], v[1], v[2]};
             Xchg::put(xchg, lane, pv6);
         }
-        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = 0.0;
+        // (the unrolled form sets the sums with the first term's product; fma(x, y, -0.0) is that product bit for bit)
+        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = -0.0;
         SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double o[6];
@@ -212,6 +213,29 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     }
 }
 
+template <int N, int M, bool AD, bool R>
+static void enqueue(const LaunchCtx &c, const BodyLaunch &bl) {
+    hipLaunchKernelGGL((hermite_body_kernel<N, M, AD, R>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg,
+                       c.cnt);
+    if (bl.rest_grid)
+        hipLaunchKernelGGL((hermite_body_kernel<N, M, AD, R>), dim3(bl.rest_grid), dim3(W), 0, c.stream, bl.rest, c.ip,
+                           c.mp, c.lg, c.cnt);
+}
+// the loop form: the only one built for this nbod, or the launcher's choice where both are (BodyLoops, device_common.hpp)
+template <int N>
+constexpr bool both_forms = N >= 12 && N <= BODY_UNROLL_MAX;
+template <int N, int M, bool AD>
+static void enqueue_form(const LaunchCtx &c, const BodyLaunch &bl, const bool rolled) {
+    if constexpr (both_forms<N>) {
+        if (rolled)
+            enqueue<N, M, AD, true>(c, bl);
+        else
+            enqueue<N, M, AD, false>(c, bl);
+    } else {
+        enqueue<N, M, AD, BodyLoops<N>::ROLLED>(c, bl);
+    }
+}
+
 // one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
@@ -220,14 +244,10 @@ static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     BodyLaunch bl;
     if (int rc = prepare_body_launch(c, G, adaptive && monb != MONB_OFF, bl)) return rc;
     // (the second launch: hermite_adap's monitor call before the loop for the systems that are not ACTIVE, launch.hpp)
-#define SWH_LAUNCH_BODY(M, AD)                                                                                         \
-    do {                                                                                                               \
-        hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp,  \
-                           c.lg, c.cnt);                                                                               \
-        if (bl.rest_grid)                                                                                              \
-            hipLaunchKernelGGL((hermite_body_kernel<N, M, AD>), dim3(bl.rest_grid), dim3(W), 0, c.stream, bl.rest,     \
-                               c.ip, c.mp, c.lg, c.cnt);                                                               \
-    } while (0)
+    // nbod 12 .. 16: the rolled form from this many ACTIVE systems on (profiles/r3/body_rolled_sweep_nbod_11_16.txt)
+    static const int rolled_from[BODY_UNROLL_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16384, 8192, 8192, 6144, 6144};
+    const bool rolled = rolled_form(c, rolled_from);
+#define SWH_LAUNCH_BODY(M, AD) enqueue_form<N, M, AD>(c, bl, rolled)
     if (adaptive) {
         if (monb == MONB_EJECTION)
             SWH_LAUNCH_BODY(MONB_EJECTION, true);

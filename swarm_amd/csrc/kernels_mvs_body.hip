@@ -22,11 +22,11 @@
 
 namespace swh {
 
-template <int N, int MONB>
+template <int N, int MONB, bool ROLLED>
 __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
-    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: loops over the bodies rolled, masses in LDS (device_common.hpp)
+    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED); // ROLLED: loops over the bodies rolled, masses in LDS (device_common.hpp)
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     // The monitor of one system, called by the whole wavefront (body_monitor.hpp), in the propagator's coordinates; a
     // system that is to be logged goes to standard coordinates for the record and back, as generic_mon_call does it
     // (generic_gpu_bppt_integrator.hpp:189-224: pass_one, conversion, pass_two, log, conversion back).
-    BodyMonitor<N, MONB> monitor;
+    BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
         monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, state, mp, lg,
@@ -284,14 +284,36 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     }
 }
 
+template <int N, int M, bool R>
+static void enqueue(const LaunchCtx &c, const BodyLaunch &bl) {
+    hipLaunchKernelGGL((mvs_body_kernel<N, M, R>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt);
+}
+// the loop form: the only one built for this nbod, or the launcher's choice where both are (BodyLoops, device_common.hpp)
+template <int N>
+constexpr bool both_forms = N >= 14 && N <= BODY_UNROLL_MAX;
+template <int N, int M>
+static void enqueue_form(const LaunchCtx &c, const BodyLaunch &bl, const bool rolled) {
+    if constexpr (both_forms<N>) {
+        if (rolled)
+            enqueue<N, M, true>(c, bl);
+        else
+            enqueue<N, M, false>(c, bl);
+    } else {
+        enqueue<N, M, BodyLoops<N>::ROLLED>(c, bl);
+    }
+}
+
 // one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
 template <int N>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
     BodyLaunch bl;
     if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
-#define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((mvs_body_kernel<N, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt)
+    // nbod 14 .. 16: the rolled form from this many ACTIVE systems on (profiles/r3/body_rolled_sweep_nbod_11_16.txt; at
+    // 12 and 13 it is 2 - 8 % behind at every size)
+    static const int rolled_from[BODY_UNROLL_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6144, 6144, 6144};
+    const bool rolled = rolled_form(c, rolled_from);
+#define SWH_LAUNCH_BODY(M) enqueue_form<N, M>(c, bl, rolled)
     switch (body_monitor_of(c.mp)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;

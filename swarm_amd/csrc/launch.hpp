@@ -138,6 +138,13 @@ inline bool within_limit(const LaunchCtx &c, const int (&limit)[SWARM_HIP_MAX_NB
     return c.ens.nbod <= SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM && c.effective_nsys() <= limit[c.ens.nbod];
 }
 
+// lane-per-body kernels built in both loop forms (BodyLoops, device_common.hpp): `from` holds, per nbod up to
+// BODY_UNROLL_MAX, the number of (ACTIVE) systems from which the rolled form is ahead, 0 = never
+inline bool rolled_form(const LaunchCtx &c, const int (&from)[BODY_UNROLL_MAX + 1]) {
+    const int n = c.ens.nbod;
+    return n > BODY_UNROLL_MAX || (from[n] > 0 && c.effective_nsys() >= from[n]);
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

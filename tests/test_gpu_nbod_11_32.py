@@ -115,6 +115,43 @@ def test_monitors_nbod_above_10(gpu, oracle, nbod):
     assert len(bytes(lm.host)) == len(mine) * ((32 + 64 * nbod + 15) // 16 * 16)
 
 
+def head_of(O, e, k):
+    """the first k systems of an ensemble as an ensemble of their own"""
+    h = O.generate(k, e.nbod)
+    for f in ("pos", "vel", "mass", "time", "state", "id"):
+        getattr(h, f)[...] = getattr(e, f)[:k]
+    return h
+
+
+@pytest.mark.parametrize("name,cfg,nbod,T", [
+    ("hermite", {"time_step": "0.01"}, 12, 0.08), ("hermite", {"time_step": "0.01"}, 16, 0.08),
+    ("hermite_adap", {"time_step_factor": "0.02", "min_time_step": "1e-6"}, 13, 0.3),
+    ("hermite", {"time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "1e9"}, 15, 0.08),
+    ("mvs", {"time_step": "0.01"}, 14, 0.08), ("mvs", {"time_step": "0.01"}, 16, 0.08),
+    ("mvs", {"time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "1e9"}, 15, 0.08),
+])
+def test_both_loop_forms_give_the_same_bits(gpu, oracle, name, cfg, nbod, T):
+    """nbod 12 .. 16, Hermite and MVS: the loops over a body's partners are unrolled for a small ensemble and rolled
+    (masses in LDS) for a large one (BodyLoops, device_common.hpp; the launcher goes by the number of systems).  The
+    first 90 systems of 16500 must come out bit for bit as the same 90 systems integrated alone."""
+    S, O = gpu, oracle
+    big = perturbed(O, 16500, nbod, seed=nbod)
+    big.time[::7] = 0.01
+    big.state[5::13] = O.DISABLED
+    small = head_of(O, big, 90)
+    hb, hs = to_host(S, big), to_host(S, small)
+    ib = run_gpu(S, hb, name, cfg, T)
+    isml = run_gpu(S, hs, name, cfg, T)
+    for f in ("pos", "vel", "time", "state"):
+        assert (getattr(hb, f)[:90] == getattr(hs, f)).all(), f
+    assert (ib.step_counts()[0][:90] == isml.step_counts()[0]).all()
+    # and the small one against the oracle, as everywhere
+    O.integrate(small, O.params(name, T, **{k: float(v) for k, v in cfg.items() if k in ("time_step", "time_step_factor", "min_time_step")}),
+                O.monitor(rmax=1e9, deactivate_on_ejection=1) if "rmax" in cfg else None)
+    assert rel_diff(hs.pos[:, 1:], small.pos[:, 1:]) < TOL and rel_diff(hs.vel[:, 1:], small.vel[:, 1:]) < TOL
+    assert (hs.state == small.state).all()
+
+
 def test_what_stops_at_nbod_10_says_so(gpu, oracle):
     """one lane per system, the printing monitors and mce_stat stop at nbod 10: a clear error, not a fallback"""
     S, O = gpu, oracle
