@@ -194,6 +194,27 @@ def test_reference_ctest_stability(cfgid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nbod", [17, 32])
+def test_cli_at_the_top_of_the_nbod_range(tmp_path, nbod):
+    """cmake/variables.cmake:55-72 accepts MAX_NBODIES up to 32: generate, the stability run and a logged run with the
+    binary writer and `query` at nbod 17 and 32 (records of 32 + 64 nbod bytes: 1120 and 2080)"""
+    p = run("integrate", "-c", os.path.join(INTEG, "Hermite.cfg"), "-d", 4, "-n", 2, "nbod=%d" % nbod, "nsys=16")
+    rows = [[float(x) for x in l.split(",")] for l in p.stdout.strip().splitlines()[1:]]
+    assert [r[0] for r in rows] == [2.0, 4.0] and all(r[1] < 1e-9 and r[3] == 16 for r in rows)
+    base = tmp_path / "log.bin"
+    run("integrate", "integrator=hermite_adap_log", "time_step_factor=170e-4", "min_time_step=0.00001",
+        "log_interval=0.25", "destination_time=1", "nsys=5", "nbod=%d" % nbod, "log_writer=binary",
+        "log_output=%s" % base)
+    blob = open(base, "rb").read()
+    rec = (32 + 64 * nbod + 15) // 16 * 16
+    assert (len(blob) - 96) % rec == 0 and (len(blob) - 96) // rec >= 5 * 4   # t0 and every 0.25
+    p = run("query", "-f", base)
+    assert len(p.stdout.splitlines()) == (nbod - 1) * ((len(blob) - 96) // rec)
+    p = run("integrate", "integrator=hermite", "time_step=0.001", "nsys=16", "nbod=33", check=False)
+    assert p.returncode != 0 and "Invalid configuration" in p.stderr      # utils.cpp:124-138
+
+
+@pytest.mark.gpu
 def test_integrate_defaults_and_failure_modes():
     run("integrate", "--defaults")                                   # cmake/test.cmake:12
     p = run("integrate", "--defaults", "--nogpu")                    # cmake/test.cmake:13; hermite_cpu name, HIP kernel
