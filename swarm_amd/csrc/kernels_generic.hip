@@ -470,7 +470,7 @@ static bool prop_prefers_body(const LaunchCtx &c, int integrator) {
 
 int launch_generic(const LaunchCtx &c, int integrator) {
     // small ensembles with nothing to monitor, or a monitor that does not print: one lane per body
-    const bool body_ok = body_monitor_of(c.mp) != MONB_NONE;
+    const bool body_ok = body_monitor_of(c.mp, c.ens.nbod) != MONB_NONE;
     int layout = 0;
     switch (integrator) {
     case SWARM_HIP_MVS: layout = choose_layout(c, body_ok, small_mvs_ensemble(c)); break;

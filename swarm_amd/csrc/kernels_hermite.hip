@@ -259,7 +259,7 @@ int launch_hermite(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, with stop_on_ejection or the ejection-or-close-encounter composite
     // (deactivation and/or snapshot records, no printf) or with log_time_interval: one lane per body (kernels_hermite_body.hip), each lane testing its own planet and
     // writing its own body's part of a record
-    const int layout = choose_layout(c, body_monitor_of(c.mp) != MONB_NONE, small_ensemble(c));
+    const int layout = choose_layout(c, body_monitor_of(c.mp, c.ens.nbod) != MONB_NONE, small_ensemble(c));
     if (layout < 0) return layout;
     if (layout == 1) return launch_hermite_body(c, adaptive);
     if (adaptive) {

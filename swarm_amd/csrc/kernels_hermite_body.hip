@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, sys, state, mp, lg,
                 [](bool, bool) {});
     };
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state
@@ -240,7 +240,7 @@ static void enqueue_form(const LaunchCtx &c, const BodyLaunch &bl, const bool ro
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
-    const int monb = body_monitor_of(c.mp);
+    const int monb = body_monitor_of(c.mp, c.ens.nbod);
     BodyLaunch bl;
     if (int rc = prepare_body_launch(c, G, adaptive && monb != MONB_OFF, bl)) return rc;
     // (the second launch: hermite_adap's monitor call before the loop for the systems that are not ACTIVE, launch.hpp)

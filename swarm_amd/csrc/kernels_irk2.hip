@@ -226,7 +226,7 @@ int launch_irk2(const LaunchCtx &c, int method, bool cpu_rules) {
     if (c.mp.kind == SWARM_HIP_MON_MCE_STAT)
         if (int rc = mce_check_attributes(c)) return rc;
     // one lane per body (kernels_irk2_body.hip) with nothing to monitor, or stop_on_ejection without printing
-    const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT && body_monitor_of(c.mp) != MONB_NONE;
+    const bool body_ok = c.mp.kind != SWARM_HIP_MON_MCE_STAT && body_monitor_of(c.mp, c.ens.nbod) != MONB_NONE;
     const int layout = choose_layout(c, body_ok, irk2_prefers_body(c));
     if (layout < 0) return layout;
     if (layout == 1) return launch_irk2_body(c, method, cpu_rules);

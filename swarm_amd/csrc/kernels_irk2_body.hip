@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
                 [](bool, bool) {});
     };
 
@@ -265,7 +265,7 @@ static int launch_body_ns(const LaunchCtx &c, bool cpu_rules) {
 #define SWH_LAUNCH_BODY(M)                                                                                              \
     hipLaunchKernelGGL((irk2_body_kernel<N, NS, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt, \
                        uround, nitmax, cpu_rules)
-    switch (body_monitor_of(c.mp)) {
+    switch (body_monitor_of(c.mp, c.ens.nbod)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
     case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;

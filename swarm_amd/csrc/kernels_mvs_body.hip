@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, sys, state, mp, lg,
                 [&](const bool who, const bool std_coordinates) {
                     if (std_coordinates)
                         to_std(who);
@@ -314,7 +314,7 @@ static int launch_body_n(const LaunchCtx &c) {
     static const int rolled_from[BODY_UNROLL_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6144, 6144, 6144};
     const bool rolled = rolled_form(c, rolled_from);
 #define SWH_LAUNCH_BODY(M) enqueue_form<N, M>(c, bl, rolled)
-    switch (body_monitor_of(c.mp)) {
+    switch (body_monitor_of(c.mp, c.ens.nbod)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
     case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto call_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
                 [](bool, bool) {});
     };
 
@@ -303,7 +303,7 @@ static int launch_body_n(const LaunchCtx &c) {
     if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
 #define SWH_LAUNCH_BODY(M) \
     hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt)
-    switch (body_monitor_of(c.mp)) {
+    switch (body_monitor_of(c.mp, c.ens.nbod)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;
     case MONB_LOG_INTERVAL: SWH_LAUNCH_BODY(MONB_LOG_INTERVAL); break;

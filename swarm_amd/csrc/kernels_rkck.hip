@@ -204,7 +204,7 @@ static bool small_rkck_ensemble(const LaunchCtx &c) {
 
 int launch_rkck(const LaunchCtx &c, bool adaptive) {
     // small ensembles with nothing to monitor, or stop_on_ejection without printing
-    const int layout = choose_layout(c, body_monitor_of(c.mp) != MONB_NONE, small_rkck_ensemble(c));
+    const int layout = choose_layout(c, body_monitor_of(c.mp, c.ens.nbod) != MONB_NONE, small_rkck_ensemble(c));
     if (layout < 0) return layout;
     if (layout == 1) return launch_rkck_body(c, adaptive);
     if (adaptive) {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
                 [](bool, bool) {});
     };
     if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
 template <int N>
 static int launch_body_n(const LaunchCtx &c, bool adaptive) {
     constexpr int G = W / N;
-    const int monb = body_monitor_of(c.mp);
+    const int monb = body_monitor_of(c.mp, c.ens.nbod);
     BodyLaunch bl;
     if (int rc = prepare_body_launch(c, G, monb != MONB_OFF, bl)) return rc;
     // (the second launch: rkck's monitor call before the loop for the systems that are not ACTIVE, launch.hpp)

@@ -126,8 +126,8 @@ inline int choose_layout(const LaunchCtx &c, bool body_ok, bool prefers_body) {
     if (body_only_nbod(c)) {
         if (body_ok) return 1;
         set_error("nbod=%d runs one lane per body (nbod > %d), which serves the no-op monitor, stop_on_ejection, "
-                  "log_time_interval and the ejection-or-close-encounter composite without verbose_on_* keys; "
-                  "mce_stat, log_transit and the printing monitors stop at nbod %d",
+                  "log_time_interval and the ejection-or-close-encounter composite; mce_stat and log_transit stop at "
+                  "nbod %d",
                   c.ens.nbod, SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM, SWARM_HIP_MAX_NBOD_LANE_PER_SYSTEM);
         return SWARM_HIP_EUNSUPPORTED;
     }

@@ -152,15 +152,74 @@ def test_both_loop_forms_give_the_same_bits(gpu, oracle, name, cfg, nbod, T):
     assert (hs.state == small.state).all()
 
 
+@pytest.mark.parametrize("nbod,name,cfg,okw", [
+    (12, "hermite", {"time_step": "0.01"}, dict(time_step=0.01)),
+    (19, "hermite_adap", {"time_step_factor": "0.02", "min_time_step": "1e-7"}, dict(time_step_factor=0.02, min_time_step=1e-7)),
+    (14, "mvs", {"time_step": "0.01"}, dict(time_step=0.01)),
+    (32, "rkck_adaptive", {"min_time_step": "1e-4", "max_time_step": "0.01", "error_tolerance": "1e-12"},
+     dict(min_time_step=1e-4, max_time_step=0.01, error_tolerance=1e-12)),
+])
+def test_verbose_on_ejection_beyond_nbod_10(gpu, oracle, nbod, name, cfg, okw):
+    """verbose_on_ejection=1 where only lane-per-body kernels exist: the lane of the first planet that meets the test
+    prints the reference's line (stop_on_ejection.hpp:120-130, 184-185); lines, stop times and records vs the oracle.
+    In every third system the two outermost planets leave together: only the inner one of them is reported."""
+    from test_gpu_mce import run, texts
+    S, O = gpu, oracle
+    e = perturbed(O, 23, nbod, seed=3, amp=1e-4)
+    r0 = 10 * 1.4 ** (nbod - 2)
+    for b in (nbod - 2, nbod - 1):
+        r = e.pos[::3, b].copy()
+        e.pos[::3, b] = r / np.sqrt((r ** 2).sum(-1))[:, None] * (1.045 * r0)
+        e.vel[::3, b] = r / np.sqrt((r ** 2).sum(-1))[:, None] * (0.005 * r0)
+    rmax = 1.05 * r0
+    cfg = dict(cfg, integrator=name, rmax=repr(rmax), deactivate_on_ejection="1", verbose_on_ejection="1", log_on_ejection="1")
+    h, lm, o, olog = run(S, O, e, cfg, 3.0, okw,
+                         O.monitor(rmax=rmax, deactivate_on_ejection=1, verbose_on_ejection=1, log_on_ejection=1))
+    assert (h.state == o.state).all() and (o.state == O.DISABLED).sum() == len(range(0, 23, 3))
+    gt, gs = texts(O, lm.host)
+    ot, os_ = texts(O, olog.bytes())
+    # (rkck calls its monitor before the loop of EVERY launch for every system, rkck_integrator.hpp:140: a second
+    # launch reports the ejected systems again, in the reference as here)
+    assert len(gt) == len(ot) and len(gs) == len(os_) and len(gt) == (16 if name == "rkck_adaptive" else 8), (len(gt), len(ot))
+    strip = lambda t: t.split(" T=")[0]                    # "_sys=%d, bod=%d" part is exact
+    assert sorted(map(strip, gt)) == sorted(map(strip, ot))
+    assert all("bod=%d," % (nbod - 2) in t for t in gt)
+    if name in ("hermite", "hermite_adap"):
+        assert gt == ot                                    # %lg prints 6 digits: identical text
+
+
+@pytest.mark.parametrize("nbod", [11, 24])
+def test_verbose_on_close_encounter_beyond_nbod_10(gpu, oracle, nbod):
+    """verbose_on_close_encounter=1: the pairs (b, d < b) are tested in order until one is met
+    (stop_on_close_encounter.hpp:108-110, 137-141); planet 5 starts next to planet 4 in every other system, and
+    planet 8 next to planet 3 as well in every fourth -- the pair (5, 4) comes first"""
+    from test_gpu_mce import run, texts
+    S, O = gpu, oracle
+    e = perturbed(O, 20, nbod, seed=8, amp=1e-4)
+    e.pos[::2, 5] = e.pos[::2, 4] * 1.002
+    e.pos[::4, 8] = e.pos[::4, 3] * 1.002
+    cfg = {"integrator": "hermite_adap_close_encounter", "time_step_factor": "0.017", "min_time_step": "1e-7",
+           "close_approach": "2.0", "deactivate_on_close_encounter": "1", "verbose_on_close_encounter": "1"}
+    h, lm, o, olog = run(S, O, e, cfg, 0.5, dict(time_step_factor=0.017, min_time_step=1e-7),
+                         O.monitor(kind=O.MON_EJECTION_OR_CLOSE, close_approach=2.0, deactivate_on_close_encounter=1,
+                                   verbose_on_close_encounter=1))
+    assert (h.state == o.state).all() and (o.state == O.DISABLED).sum() == 10
+    gt, _ = texts(O, lm.host)
+    ot, _ = texts(O, olog.bytes())
+    assert gt == ot and len(gt) == 10
+    assert all("j=4 i=5" in t for t in gt)
+
+
 def test_what_stops_at_nbod_10_says_so(gpu, oracle):
-    """one lane per system, the printing monitors and mce_stat stop at nbod 10: a clear error, not a fallback"""
+    """one lane per system, mce_stat and log_transit stop at nbod 10: a clear error, not a fallback"""
     S, O = gpu, oracle
     h = to_host(S, perturbed(O, 8, 11, seed=1))
-    for extra in ({"lane_mode": "1"}, {"verbose_on_ejection": "1", "rmax": "5"}):
-        integ = S.Integrator.create(S.config(dict({"integrator": "hermite", "time_step": "0.01"}, **extra)))
+    for cfg in ({"integrator": "hermite", "time_step": "0.01", "lane_mode": "1"},
+                {"integrator": "hermite_adap_transit", "time_step_factor": "0.02", "min_time_step": "1e-6", "nbod": "11", "time_step": "0.01"}):
+        integ = S.Integrator.create(S.config(cfg))
         integ.set_ensemble(h.clone())
         integ.set_destination_time(0.1)
-        if "lane_mode" in extra:
+        if "lane_mode" in cfg:
             integ.integrate()          # lane_mode=1 cannot be honoured beyond nbod 10: one lane per body is what runs
             continue
         with pytest.raises(S.capi.SwarmHipError, match="one lane per body"):
