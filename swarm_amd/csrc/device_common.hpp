@@ -304,7 +304,7 @@ struct LaneExchange {
 // nbod - 1 registers: every LDS load of an exchange is in flight at once, which is what a lone wavefront on its SIMD
 // needs, at the price of registers (nbod 13: 256 VGPRs + 29 ... 98 AGPRs, one wavefront per SIMD whatever the ensemble
 // size; nbod 32: 256 + 256 + 1.0 ... 1.4 KB of scratch per lane, and sixteen such instantiations of every kernel would
-// take the library from 35 to 150 MB).  ROLLED, eight partners per trip, the masses read from a row in LDS: half the
+// take the library from 35 to 150 MB).  ROLLED, eight or sixteen partners per trip, the masses read from a row in LDS: half the
 // registers, so several wavefronts share a SIMD and hide one another's LDS latency.  Up to BODY_UNROLL_MAX the kernels
 // are unrolled (instruction for instruction what they were before the rolled form existed), beyond it (17 .. 32) rolled;
 // the Hermite kernels are built in BOTH forms for nbod 12 .. 16 and MVS for 14 .. 16, where the rolled form is 10 - 30 % ahead
@@ -316,7 +316,9 @@ constexpr int BODY_UNROLL_MAX = 16;
 template <int N>
 struct BodyLoops {
     static constexpr bool ROLLED = N > BODY_UNROLL_MAX; // the form of a kernel that is built in one form only
-    static constexpr int trip(const bool rolled) { return rolled ? 8 : N; }
+    // partners per trip of a rolled loop: 8, or 16 where a kernel is ahead with it (rkck, irk2, verlet: 2 - 10 %,
+    // at nbod 17 -- one trip -- 25 %; the others lose up to 30 % there; profiles/r3/body_rolled_trip_8_vs_16.txt)
+    static constexpr int trip(const bool rolled, const int partners = 8) { return rolled ? partners : N; }
     static constexpr int outer_trip(const bool rolled) { return rolled ? 1 : N; } // around a SWH_BODY_LOOP
 };
 #define SWH_BODY_LOOP _Pragma("unroll BODY_TRIP")

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
     constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
-    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED);
+    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED, 16);
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;

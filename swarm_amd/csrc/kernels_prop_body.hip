@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     constexpr bool EJ = MONB != MONB_OFF;
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
     constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
-    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED);
+    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED, KIND == SWARM_HIP_VERLET ? 16 : 8);
     [[maybe_unused]] constexpr int BODY_TRIP_OUTER = BodyLoops<N>::outer_trip(ROLLED);
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
