@@ -307,9 +307,10 @@ struct LaneExchange {
 // take the library from 35 to 150 MB).  ROLLED, eight or sixteen partners per trip, the masses read from a row in LDS: half the
 // registers, so several wavefronts share a SIMD and hide one another's LDS latency.  Up to BODY_UNROLL_MAX the kernels
 // are unrolled (instruction for instruction what they were before the rolled form existed), beyond it (17 .. 32) rolled;
-// the Hermite kernels are built in BOTH forms for nbod 12 .. 16 and MVS for 14 .. 16, where the rolled form is 10 - 30 % ahead
-// once there is more than about a wavefront and a half per SIMD (profiles/r3/body_rolled_sweep_nbod_11_16.txt) and
-// the launcher picks by the number of ACTIVE systems; rkck, irk2 and verlet lose with it at every size and are not.
+// the Hermite kernels are built in BOTH forms for nbod 12 .. 16, MVS for 14 .. 16, euler, midpoint and hermite_prop for
+// 13 .. 16, where the rolled form is 10 - 30 % ahead once there is more than about a wavefront and a half per SIMD
+// (profiles/r3/body_rolled_sweep_nbod_11_16.txt, prop_rolled_sweep.txt) and the launcher picks by the number of
+// ACTIVE systems; rkck, irk2 and verlet lose with it at every size and are not.
 // Both forms perform the same operations in the same order: bit-identical results (tests/test_gpu_nbod_11_32.py).
 // SWH_BODY_LOOP goes before such a loop; it expects `BODY_TRIP` (= BodyLoops<N>::trip(ROLLED)) in scope.
 constexpr int BODY_UNROLL_MAX = 16;

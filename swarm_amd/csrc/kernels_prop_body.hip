@@ -18,12 +18,12 @@
 
 namespace swh {
 
-template <int N, int KIND, int MONB>
+template <int N, int KIND, int MONB, bool ROLLED>
 __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF;
     constexpr bool FOLD = N >= HERMITE_FOLD_FROM; // hermite_step<N>'s form from nbod 9 on
-    constexpr bool ROLLED = BodyLoops<N>::ROLLED; // nbod 17 .. 32: partner loops rolled, masses in LDS (device_common.hpp)
+    // ROLLED: partner loops rolled, masses in LDS (device_common.hpp)
     constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED, KIND == SWARM_HIP_VERLET ? 16 : 8);
     [[maybe_unused]] constexpr int BODY_TRIP_OUTER = BodyLoops<N>::outer_trip(ROLLED);
     const int lane = threadIdx.x;
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
             const double pv6[6] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2]};
             Xchg6::put(xchg6, lane, pv6);
         }
-        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = 0.0;
+        // (the unrolled form sets the sums with the first term's product; fma(x, y, -0.0) is that product bit for bit)
+        if constexpr (ROLLED) a[0] = a[1] = a[2] = jk[0] = jk[1] = jk[2] = -0.0;
         SWH_BODY_LOOP
         for (int q = 0; q < N - 1; q++) {
             double o[6];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
         return verlet_step_of(sum, ip.timestep_scale, ip.max_timestep);
     };
     // the monitor of one system, called by the whole wavefront (body_monitor.hpp)
-    BodyMonitor<N, MONB> monitor;
+    BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto call_monitor = [&](const bool take_part) {
         monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
@@ -295,14 +296,38 @@ __global__ __launch_bounds__(64) void prop_body_kernel(EnsView e, IntParams ip, 
     }
 }
 
+template <int N, int KIND, int M, bool R>
+static void enqueue(const LaunchCtx &c, const BodyLaunch &bl) {
+    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M, R>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg,
+                       c.cnt);
+}
+// the loop form: the only one built for this nbod, or the launcher's choice where both are (BodyLoops,
+// device_common.hpp): euler, midpoint and hermite_prop at nbod 13 .. 16; verlet's rolled form is behind at every size
+template <int N, int KIND>
+constexpr bool both_forms = KIND != SWARM_HIP_VERLET && N >= 13 && N <= BODY_UNROLL_MAX;
+template <int N, int KIND, int M>
+static void enqueue_form(const LaunchCtx &c, const BodyLaunch &bl, const bool rolled) {
+    if constexpr (both_forms<N, KIND>) {
+        if (rolled)
+            enqueue<N, KIND, M, true>(c, bl);
+        else
+            enqueue<N, KIND, M, false>(c, bl);
+    } else {
+        enqueue<N, KIND, M, BodyLoops<N>::ROLLED>(c, bl);
+    }
+}
+
 // one wavefront per workgroup, so that a small ensemble spreads over as many CUs as it has wavefronts
 template <int N, int KIND>
 static int launch_body_n(const LaunchCtx &c) {
     constexpr int G = W / N;
     BodyLaunch bl;
     if (int rc = prepare_body_launch(c, G, false, bl)) return rc;
-#define SWH_LAUNCH_BODY(M) \
-    hipLaunchKernelGGL((prop_body_kernel<N, KIND, M>), dim3(bl.grid), dim3(W), 0, c.stream, bl.view, c.ip, c.mp, c.lg, c.cnt)
+    // nbod 13 .. 16: the rolled form from this many ACTIVE systems on (profiles/r3/prop_rolled_sweep.txt)
+    static const int from_12288[BODY_UNROLL_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 12288, 12288, 12288, 12288};
+    static const int from_8192[BODY_UNROLL_MAX + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8192, 8192, 8192, 8192};
+    const bool rolled = rolled_form(c, KIND == SWARM_HIP_HERMITE_PROP ? from_8192 : from_12288);
+#define SWH_LAUNCH_BODY(M) enqueue_form<N, KIND, M>(c, bl, rolled)
     switch (body_monitor_of(c.mp, c.ens.nbod)) {
     case MONB_EJECTION: SWH_LAUNCH_BODY(MONB_EJECTION); break;
     case MONB_EJECTION_OR_CLOSE: SWH_LAUNCH_BODY(MONB_EJECTION_OR_CLOSE); break;

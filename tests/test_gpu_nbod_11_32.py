@@ -129,9 +129,12 @@ def head_of(O, e, k):
     ("hermite", {"time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "1e9"}, 15, 0.08),
     ("mvs", {"time_step": "0.01"}, 14, 0.08), ("mvs", {"time_step": "0.01"}, 16, 0.08),
     ("mvs", {"time_step": "0.01", "deactivate_on_ejection": "1", "rmax": "1e9"}, 15, 0.08),
+    ("euler", {"time_step": "0.001"}, 13, 0.008), ("midpoint", {"time_step": "0.001"}, 16, 0.008),
+    ("hermite_prop", {"time_step": "0.001"}, 14, 0.008),
+    ("hermite_prop", {"time_step": "0.001", "deactivate_on_ejection": "1", "rmax": "1e9"}, 16, 0.008),
 ])
 def test_both_loop_forms_give_the_same_bits(gpu, oracle, name, cfg, nbod, T):
-    """nbod 12 .. 16, Hermite and MVS: the loops over a body's partners are unrolled for a small ensemble and rolled
+    """nbod 12 .. 16, Hermite, MVS, euler, midpoint, hermite_prop: the loops over a body's partners are unrolled for a small ensemble and rolled
     (masses in LDS) for a large one (BodyLoops, device_common.hpp; the launcher goes by the number of systems).  The
     first 90 systems of 16500 must come out bit for bit as the same 90 systems integrated alone."""
     S, O = gpu, oracle
