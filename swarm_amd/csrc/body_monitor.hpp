@@ -2,8 +2,8 @@
 // (stop_on_ejection.hpp:108-201), log_time_interval (log_time_interval.hpp:98-119) and the
 // ejection-or-close-encounter composite (composites.hpp:145-222, stop_on_close_encounter.hpp:101-142) -- without
 // printing up to nbod 10, where launches with verbose_on_* keys go to the lane-per-system kernels, and with the
-// reference's lprintf lines beyond.  The N lanes of a system act as one monitor object: every lane tests its own planet (and, for close
-// encounters, the pairs (b, d), 1 <= d < b), ballots share the verdicts, every lane keeps the object's state
+// reference's lprintf lines beyond.  The N lanes of a system act as one monitor object: every lane tests its own planet
+// (and, for close encounters, the pairs (b, d), 1 <= d < b), ballots share the verdicts, every lane keeps the object's state
 // (next_log_time, the close-encounter flag) and the lanes write a snapshot record together (log_system_body).
 // The tests are the scalar helpers the lane-per-system monitors use (ej_test_quiet, ce_test_quiet), so outcomes,
 // stop steps and records are the lane-per-system kernels' (tests/test_gpu_body_logging.py).
@@ -110,7 +110,8 @@ struct BodyMonitor {
             }
             const unsigned long long ce_hits = __ballot(ce_part && ce) & group_mask;
             const bool ce_now = ce_hits != 0;
-            if constexpr (PRINTS) { // the pairs (b, d < b) are tested in order until one is met (stop_on_close_encounter.hpp:108-110): it alone prints
+            // the pairs (b, d < b) are tested in order until one is met (stop_on_close_encounter.hpp:108-110): it alone prints
+            if constexpr (PRINTS) {
                 if (mp.ce_verbose && ce_part && ce && star + b == __ffsll((long long)ce_hits) - 1)
                     body_close_line(lg, number, t, first_d, b, first_sep);
             }

@@ -304,8 +304,8 @@ struct LaneExchange {
 // nbod - 1 registers: every LDS load of an exchange is in flight at once, which is what a lone wavefront on its SIMD
 // needs, at the price of registers (nbod 13: 256 VGPRs + 29 ... 98 AGPRs, one wavefront per SIMD whatever the ensemble
 // size; nbod 32: 256 + 256 + 1.0 ... 1.4 KB of scratch per lane, and sixteen such instantiations of every kernel would
-// take the library from 35 to 150 MB).  ROLLED, eight or sixteen partners per trip, the masses read from a row in LDS: half the
-// registers, so several wavefronts share a SIMD and hide one another's LDS latency.  Up to BODY_UNROLL_MAX the kernels
+// take the library from 35 to 150 MB).  ROLLED, eight or sixteen partners per trip, the masses read from a row in LDS:
+// half the registers, so several wavefronts share a SIMD and hide one another's LDS latency.  Up to BODY_UNROLL_MAX the kernels
 // are unrolled (instruction for instruction what they were before the rolled form existed), beyond it (17 .. 32) rolled;
 // the Hermite kernels are built in BOTH forms for nbod 12 .. 16, MVS for 14 .. 16, euler, midpoint and hermite_prop for
 // 13 .. 16, where the rolled form is 10 - 30 % ahead once there is more than about a wavefront and a half per SIMD

@@ -12,6 +12,9 @@
 // a body accumulates its partners in increasing index order, first term by multiplication, and
 // (p_j - p_i), (v_j - v_i) enter the pair quantities only through products that are even in the
 // sign, so both kernels give bit-identical ensembles (tests/test_gpu_hermite.py).
+// The loops over the partners exist in two forms (BodyLoops, device_common.hpp): unrolled with the masses in registers
+// (ROLLED = false: nbod <= 16) and rolled with the masses in LDS (nbod >= 17, and nbod 12 .. 16 for large ensembles,
+// where both are built and launch_body_n picks); the same operations in the same order.
 // Used by launch_hermite for the no-op monitor (Hermite.cfg as shipped: no deactivate/log keys), MONB = 0; for
 // stop_on_ejection without printing, MONB = 1: every lane tests its own planet (stop_on_ejection.hpp:108-138), the
 // lanes of a system share the verdict through one ballot and, with log_on_ejection, write the snapshot record
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(64) void hermite_body_kernel(EnsView e, IntParams i
     BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, sys, state, mp, lg,
+        monitor(take_part, b, base, group_mask, p, v, m_own,
+                [&](const int d) { return partner_mass(d, (base + d) & (W - 1)); }, t, id, sys, state, mp, lg,
                 [](bool, bool) {});
     };
     // hermite_adap.hpp:130: the adaptive kernel calls the monitor once before the loop, whatever the state

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(64) void irk2_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
-                [](bool, bool) {});
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t,
+                id, sys, state, mp, lg, [](bool, bool) {});
     };
 
     unsigned long long steps = 0;

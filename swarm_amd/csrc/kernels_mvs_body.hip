@@ -26,7 +26,7 @@ template <int N, int MONB, bool ROLLED>
 __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, MonParams mp, LogBuf lg, Counters cnt) {
     constexpr int G = W / N; // systems per wavefront
     constexpr bool EJ = MONB != MONB_OFF; // some monitor is bound
-    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED); // ROLLED: loops over the bodies rolled, masses in LDS (device_common.hpp)
+    constexpr int BODY_TRIP = BodyLoops<N>::trip(ROLLED); // ROLLED: loops over the bodies rolled, masses in LDS
     const int lane = threadIdx.x;
     const int g = lane / N, b = lane - g * N;
     int sys;
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(64) void mvs_body_kernel(EnsView e, IntParams ip, M
     BodyMonitor<N, MONB, ROLLED> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, sys, state, mp, lg,
-                [&](const bool who, const bool std_coordinates) {
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return mass_of(d); }, t, id, sys, state,
+                mp, lg, [&](const bool who, const bool std_coordinates) {
                     if (std_coordinates)
                         to_std(who);
                     else

@@ -95,8 +95,8 @@ __global__ __launch_bounds__(64) void rkck_body_kernel(EnsView e, IntParams ip, 
     BodyMonitor<N, MONB> monitor;
     monitor.init(t);
     auto ejection_monitor = [&](const bool take_part) {
-        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t, id, sys, state, mp, lg,
-                [](bool, bool) {});
+        monitor(take_part, b, base, group_mask, p, v, m_own, [&](const int d) { return partner_mass(d, base + d); }, t,
+                id, sys, state, mp, lg, [](bool, bool) {});
     };
     if (EJ) ejection_monitor(valid); // rkck_integrator.hpp:140: once before the loop, every system
 
