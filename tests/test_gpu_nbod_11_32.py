@@ -115,6 +115,24 @@ def test_monitors_nbod_above_10(gpu, oracle, nbod):
     assert len(bytes(lm.host)) == len(mine) * ((32 + 64 * nbod + 15) // 16 * 16)
 
 
+@pytest.mark.parametrize("nbod", [17, 22, 32])
+@pytest.mark.parametrize("nsys", [1, 2, 3])
+def test_fewer_systems_than_a_wavefront_holds(gpu, oracle, nbod, nsys):
+    """one, two or three systems where a wavefront holds three or two: idle groups of lanes, a single workgroup"""
+    S, O = gpu, oracle
+    for name, cfg, okw in (("hermite", {"time_step": "0.01"}, dict(time_step=0.01)),
+                           ("mvs", {"time_step": "0.01"}, dict(time_step=0.01)),
+                           ("rkck_adaptive", {"min_time_step": "1e-4", "max_time_step": "0.01", "error_tolerance": "1e-12"},
+                            dict(min_time_step=1e-4, max_time_step=0.01, error_tolerance=1e-12))):
+        e = perturbed(O, nsys, nbod, seed=nbod + nsys)
+        h = to_host(S, e)
+        run_gpu(S, h, name, cfg, 0.3)
+        O.integrate(e, O.params(name, 0.3, **okw))
+        assert (h.state == e.state).all() and (h.state == O.INACTIVE).all()
+        assert rel_diff(h.pos[:, 1:], e.pos[:, 1:]) < TOL and rel_diff(h.vel[:, 1:], e.vel[:, 1:]) < TOL, name
+        np.testing.assert_allclose(h.time, e.time, rtol=1e-12)
+
+
 def head_of(O, e, k):
     """the first k systems of an ensemble as an ensemble of their own"""
     h = O.generate(k, e.nbod)
