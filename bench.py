@@ -169,7 +169,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        raise SystemExit("bench.py needs a GPU (rank %d of %d; the product path has no CPU fallback)" % (rank, world))
     if args.rehearse_one_gpu:
         local_rank = 0
     if local_rank >= torch.cuda.device_count():

@@ -1,6 +1,6 @@
 """bench.py's own rank launcher, without a GPU: `python bench.py --gpus 2` must start two ranks as child processes
 (torch.distributed.run) and hand their status back.  Here every rank stops at "needs a GPU", which is the evidence:
-the message appears once per rank and the exit status is the launcher's failure status."""
+the message names the rank and the world size of 2, and the exit status is the launcher's failure status."""
 import os
 import subprocess
 import sys
@@ -19,5 +19,7 @@ def test_bench_gpus_n_starts_n_ranks_without_a_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a GPU") == 2, p.stderr[-3000:]
+    # (the elastic agent ends the other rank as soon as the first has failed: that one may not get to its own message)
+    said = p.stderr.count("bench.py needs a GPU")
+    assert 1 <= said <= 2 and " of 2;" in p.stderr, p.stderr[-3000:]
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]      # no JSON line from a failed run
