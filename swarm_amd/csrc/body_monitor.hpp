@@ -29,26 +29,26 @@ inline int body_monitor_of(const MonParams &mp, const int nbod) {
 }
 
 // the lines of verbose_on_ejection / verbose_on_close_encounter (stop_on_ejection.hpp:120-130,
-// stop_on_close_encounter.hpp:137-141), out of line: the operations and texts of ej_test_body / ce_check
-static __device__ __noinline__ void body_ejection_line(const LogBuf &lg, const int number, const int b, const double t,
-                                                       const double x, const double y, const double z, const double vx,
-                                                       const double vy, const double vz, const double m) {
+// stop_on_close_encounter.hpp:137-141): the operations and texts of ej_test_body / ce_check, written in line
+// (log_printf_inline, device_common.hpp: a call would cost the kernels 4 - 9 % even where nothing is printed)
+__device__ __forceinline__ void body_ejection_line(const LogBuf &lg, const int number, const int b, const double t,
+                                                   const double (&p)[3], const double (&v)[3], const double m) {
 #pragma clang fp contract(off)
-    const double r = sqrt(x * x + y * y + z * z);
-    const double speed_sq = vx * vx + vy * vy + vz * vz;
+    const double r = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const double speed_sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
     const double epp = 0.5 * speed_sq * r / m - 1.;
     const double energy = 0.5 * speed_sq - m / r;
     if (fabs(epp) < 1e-4)
-        SWH_LPRINTF(lg, "Orbit is nearly parabolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
-                    parg(number), parg(b), parg(t), parg(r), parg(energy), parg(epp));
+        SWH_LPRINTF_INLINE(lg, "Orbit is nearly parabolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
+                           parg(number), parg(b), parg(t), parg(r), parg(energy), parg(epp));
     else
-        SWH_LPRINTF(lg, "Orbit is hyperbolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n", parg(number),
-                    parg(b), parg(t), parg(r), parg(energy), parg(epp));
+        SWH_LPRINTF_INLINE(lg, "Orbit is hyperbolic: _sys=%d, bod=%d, T=%lg r=%lg energy=%lg energy*r/GM=%lg.\n",
+                           parg(number), parg(b), parg(t), parg(r), parg(energy), parg(epp));
 }
-static __device__ __noinline__ void body_close_line(const LogBuf &lg, const int number, const double t, const int j,
-                                                    const int i, const double d) {
-    SWH_LPRINTF(lg, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", parg(number), parg(t), parg(j), parg(i),
-                parg(d));
+__device__ __forceinline__ void body_close_line(const LogBuf &lg, const int number, const double t, const int j,
+                                                const int i, const double d) {
+    SWH_LPRINTF_INLINE(lg, "Close apporach detected: sys=%d, T=%f j=%d i=%d  d=%lg.\n", parg(number), parg(t), parg(j),
+                       parg(i), parg(d));
 }
 
 template <int N, int MONB, bool ROLLED = BodyLoops<N>::ROLLED>
@@ -86,7 +86,7 @@ struct BodyMonitor {
             ej_met = hits != 0;
             if constexpr (PRINTS) { // the planets are tested in index order until one is met (L184-185): it alone prints
                 if (mp.ej_verbose && ej && star + b == __ffsll((long long)hits) - 1)
-                    body_ejection_line(lg, number, b, t, p[0], p[1], p[2], v[0], v[1], v[2], m_own);
+                    body_ejection_line(lg, number, b, t, p, v, m_own);
             }
             want = take_part && ej_met && mp.ej_log;
         }
@@ -94,26 +94,35 @@ struct BodyMonitor {
             // skipped for a system whose ejection is about to be logged: the composite's short-circuit ||
             const bool ce_part = take_part && !want;
             bool ce = false;
-            [[maybe_unused]] int first_d = 0;
-            [[maybe_unused]] double first_sep = 0.;
+            [[maybe_unused]] int first_d = 0; // PRINTS: the first d < b that is close to b, 0 = none: stands for `ce`
             if (mp.ce_any) {
                 SWH_BODY_LOOP
                 for (int d = 1; d < N - 1; d++) {
                     const double pj[3] = {__shfl(p[0], star + d), __shfl(p[1], star + d), __shfl(p[2], star + d)};
                     double sep;
                     const bool c = ce_test_quiet(p, pj, m_own, mass(d), mass(0), mp, sep);
-                    if constexpr (PRINTS) {
-                        if (d < b && c && !ce) first_d = d, first_sep = sep;
-                    }
-                    ce = ce || (d < b && c);
+                    if constexpr (PRINTS)
+                        first_d = (first_d == 0 && d < b && c) ? d : first_d;
+                    else
+                        ce = ce || (d < b && c);
                 }
+                if constexpr (PRINTS) ce = first_d != 0;
             }
             const unsigned long long ce_hits = __ballot(ce_part && ce) & group_mask;
             const bool ce_now = ce_hits != 0;
-            // the pairs (b, d < b) are tested in order until one is met (stop_on_close_encounter.hpp:108-110): it alone prints
+            // the pairs (b, d < b) are tested in order until one is met (stop_on_close_encounter.hpp:108-110): it alone
+            // prints; its separation is formed again here, the whole wavefront together (the shuffles need every lane)
             if constexpr (PRINTS) {
-                if (mp.ce_verbose && ce_part && ce && star + b == __ffsll((long long)ce_hits) - 1)
-                    body_close_line(lg, number, t, first_d, b, first_sep);
+                const bool printer = mp.ce_verbose && ce_part && ce && star + b == __ffsll((long long)ce_hits) - 1;
+                if (__any(printer)) {
+                    const double pj[3] = {__shfl(p[0], star + first_d), __shfl(p[1], star + first_d),
+                                          __shfl(p[2], star + first_d)};
+                    if (printer) {
+#pragma clang fp contract(off)
+                        const double dx = p[0] - pj[0], dy = p[1] - pj[1], dz = p[2] - pj[2];
+                        body_close_line(lg, number, t, first_d, b, sqrt(dx * dx + dy * dy + dz * dz));
+                    }
+                }
             }
             if (ce_part) ce_met = ce_now;
             want = take_part && ((mp.ej_log && ej_met) || (mp.ce_log && ce_met));

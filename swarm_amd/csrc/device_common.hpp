@@ -591,6 +591,45 @@ static __device__ __noinline__ void log_printf_lane(const LogBuf &lg, const char
         at += al;
     }
 }
+// The same record written in line: no call, no argument array on the stack.  For the rare lines of the body monitors
+// (body_monitor.hpp): a call in a lane-per-body kernel costs its hot loop 4 - 9 % even if it is never taken
+// (profiles/r3/body_monitor_print_path_ab.txt).  The loops over the text stay rolled.
+template <int NFMT, int NARGS>
+__device__ __forceinline__ void log_printf_inline(const LogBuf &lg, const char (&fmt)[NFMT], const PArg (&a)[NARGS]) {
+    int at = 8 + NFMT;
+#pragma unroll
+    for (int k = 0; k < NARGS; k++) {
+        const int al = a[k].is_double ? 8 : 4;
+        at = (at + al - 1) / al * al + al;
+    }
+    const int len = (at + 15) / 16 * 16;
+    uint8_t *r = log_reserve_lane(lg, len);
+    if (!r) return;
+    atomicAdd(lg.cursor + 2, 1);
+#pragma unroll 1
+    for (int k = 8; k < len; k += 4) *reinterpret_cast<int32_t *>(r + k) = 0;
+    reinterpret_cast<int32_t *>(r)[0] = -2; // MSG_PRINTF
+    reinterpret_cast<int32_t *>(r)[1] = len;
+#pragma unroll 1
+    for (int k = 0; k < NFMT; k++) r[8 + k] = (uint8_t)fmt[k];
+    at = 8 + NFMT;
+#pragma unroll
+    for (int k = 0; k < NARGS; k++) {
+        const int al = a[k].is_double ? 8 : 4;
+        at = (at + al - 1) / al * al;
+        if (a[k].is_double)
+            *reinterpret_cast<double *>(r + at) = a[k].d;
+        else
+            *reinterpret_cast<int32_t *>(r + at) = a[k].i;
+        at += al;
+    }
+}
+#define SWH_LPRINTF_INLINE(lg, fmt, ...)           \
+    do {                                           \
+        const PArg _a[] = {__VA_ARGS__};           \
+        log_printf_inline(lg, fmt, _a);            \
+    } while (0)
+
 #define SWH_LPRINTF(lg, fmt, ...)                                  \
     do {                                                           \
         const PArg _a[] = {__VA_ARGS__};                           \
